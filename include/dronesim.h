@@ -1,0 +1,124 @@
+/*
+ * dronesim.h -- C ABI of the MI355X-native batched drone_env hot path.
+ *
+ * The reference (AndreuMatoses/scalable-collision-avoidance-RL) is pure Python
+ * and has no FFI layer; its boundary for this path is the duck-typed surface of
+ * class `drones` (drone_env.py:53-401).  Each entry point below replaces one
+ * reference method, batched over E independent environments, and is what a
+ * Python `ctypes` binding of that class loads (see INTEGRATION.md and
+ * scalable_collision_avoidance_rl_amd/_native.py).
+ *
+ * Conventions
+ *  - Every buffer is CALLER-OWNED DEVICE memory (hipMalloc / a torch tensor's
+ *    data_ptr()), contiguous, env-major:
+ *        pos, vel, act      float32 [E][N][2]
+ *        reward, true_reward float32 [E][N]
+ *        z                  float32 [E][N][k+1][c]   (c = 2 or 5)
+ *        nbr_idx            int32   [E][N][k+1]      slot 0 = i, then the real
+ *                                                    neighbours by ascending d_ij,
+ *                                                    unused slots = -1
+ *        n_coll             int32   [E]   ordered colliding pairs (always even)
+ *        done               uint8   [E]
+ *        t                  int32   [E]   internal_t of every env
+ *  - The library allocates nothing persistent, never synchronises the host and
+ *    enqueues all work on `stream` (a hipStream_t passed as void*; NULL = the
+ *    null stream).  Pass the stream the neighbouring kernels run on.
+ *  - Return value: 0 on success, a negative DRONESIM_E* code otherwise; nothing
+ *    is thrown across the ABI.  dronesim_last_error() gives a thread-local
+ *    description of the last failure.
+ *  - Re-entrant; no global mutable state besides that thread-local string.
+ *  - One process drives one GPU; multi-GPU runs shard the E axis across
+ *    processes (env_base keeps random streams independent of the sharding).
+ */
+#ifndef DRONESIM_H
+#define DRONESIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRONESIM_VERSION 100           /* 0.1.0 */
+#define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
+#define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
+
+#define DRONESIM_OK 0
+#define DRONESIM_EINVAL (-1)           /* null pointer / size out of range */
+#define DRONESIM_EUNSUPPORTED (-2)     /* k or N beyond the compiled kernels */
+#define DRONESIM_ELAUNCH (-3)          /* HIP launch error (see last_error) */
+
+/* Constants of one `drones` object (shared by all E envs).
+ * Scalars: drone_env.py:27-30 (dim, dt, max_time_steps), :72 (collision_weight),
+ * :269-270 (q = 2*dt, b = collision_weight*dt), :251 (done radius 0.2), :386 (1.1).
+ * Arrays (device pointers): goal ring xF and safety distance d_hat from
+ * generate_formation (:115-153), deltas after the clip of :85-89, radii (:75). */
+typedef struct DroneParams {
+    int32_t N;              /* n_agents, 2..DRONESIM_MAX_AGENTS                     */
+    int32_t k;              /* k_closest, 1..min(N-1, DRONESIM_MAX_K)               */
+    int32_t c;              /* columns of a z row: 2 (simplify_zstate) or 5         */
+    int32_t max_steps;      /* max_time_steps (200)                                 */
+    float dt;               /* 0.05                                                 */
+    float q;                /* formation weight, 2*dt                               */
+    float b;                /* collision weight, collision_weight*dt                */
+    float done_radius;      /* 0.2                                                  */
+    float ghost_factor;     /* 1.1                                                  */
+    /* host-known bounds of the arrays below (the library never reads device
+       memory on the host): used to pick the kernel variant and the early-out
+       radius.  d_hat_min must be > 0.                                              */
+    float d_hat_min;
+    float delta_max;
+    float radius_max;
+    const float *xF;        /* [N][2] */
+    const float *d_hat;     /* [N]    */
+    const float *delta;     /* [N]    */
+    const float *radius;    /* [N]    */
+} DroneParams;
+
+/* drones.step(actions)                                   drone_env.py:214-258
+ * Integrates pos += dt*act, vel = act IN PLACE, then evaluates rewards(),
+ * distance_data() and localized_states() on the new state (:260-401), the
+ * termination test (:247-254) and t += 1 (:256).                                  */
+int dronesim_step(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
+                  float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                  int32_t *n_coll, uint8_t *done, int E, void *stream);
+
+/* drones.rewards(state, ...) without integration         drone_env.py:260-293
+ * (what init_agents runs to produce the first z_states / Ni, :208-210).
+ * reward, true_reward, n_coll may be NULL (not written).  mask NULL = every env,
+ * otherwise only envs with mask[e] != 0 are evaluated and written.                */
+int dronesim_observe(const DroneParams *p, const float *pos, const float *vel,
+                     float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                     int32_t *n_coll, const uint8_t *mask, int E, void *stream);
+
+/* drones.reset() / init_agents(): state part             drone_env.py:98-102, 171-205
+ * Draws N distinct nodes of the div_x x div_y lattice (node (a,b) -> (a*pitch,
+ * b*pitch), pitch = 2*1.1*l) per env with a counter-based Philox4x32-10 stream
+ * keyed by (seed, env_base + e, episode[e], agent, round); zeroes vel and t and
+ * increments episode[e] (int32 [E], device, in/out: how many times env e has been
+ * reset -- kept on the device so that a captured hipGraph replays fresh streams).
+ * mask as above.  node_out (int32 [E][N], node = a*div_y + b) may be NULL.
+ * Follow with dronesim_observe() to refresh z / nbr_idx (:208-210).               */
+int dronesim_reset(const DroneParams *p, int div_x, int div_y, float pitch,
+                   uint64_t seed, int64_t env_base, const uint8_t *mask,
+                   float *pos, float *vel, int32_t *t, int32_t *episode, int32_t *node_out,
+                   int E, void *stream);
+
+/* T consecutive drones.step() calls in ONE launch (the `while not finished` loop
+ * of train_problem.py:82-107 with the actions known up front, e.g. RandomAgent,
+ * SAC_agents.py:9-22).  act is [T][E][N][2]; every per-step output of
+ * dronesim_step is written for every step into [T][...] buffers laid out as T
+ * consecutive copies of the per-step layout; pos/vel/t hold the final state.
+ * Envs are NOT reset inside the rollout (t keeps counting, done stays set).       */
+int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
+                     float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                     int32_t *n_coll, uint8_t *done, int E, int T, void *stream);
+
+const char *dronesim_last_error(void);
+const char *dronesim_error_string(int code);
+int dronesim_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRONESIM_H */

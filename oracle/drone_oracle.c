@@ -344,16 +344,17 @@ uint32_t oracle_philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
 }
 
 /* Draw N distinct nodes out of M = div_x*div_y for env `env_gid`:
- *   round r: every unsettled agent i proposes node = mulhi32(philox(i, r, env_gid, counter_lo;
- *            key = seed_lo ^ counter_hi, seed_hi).word0, M);
+ *   round r: every unsettled agent i proposes node = mulhi32(philox(ctr = (i, r, env_gid,
+ *            episode[e]); key = (seed_lo, seed_hi)).word0, M), episode[e] = number of resets
+ *            env e has seen so far (incremented here);
  *   i settles iff no settled agent holds that node and no unsettled agent
  *   with a smaller index proposed it in this round.
  * Positions = (idx*pitch, jdx*pitch), node = idx*div_y + jdx (:197-200).
  * mask NULL = reset every env; otherwise only envs with mask[e] != 0.
  * returns 0, or -2 if M < N, -3 if the round cap is hit. */
-int oracle_reset(int N, int div_x, int div_y, double pitch, uint64_t seed, uint64_t counter,
+int oracle_reset(int N, int div_x, int div_y, double pitch, uint64_t seed,
                  int64_t env_base, const uint8_t *mask,
-                 double *pos, double *vel, int32_t *t, int32_t *node_out, int E)
+                 double *pos, double *vel, int32_t *t, int32_t *episode, int32_t *node_out, int E)
 {
     const uint64_t M = (uint64_t)div_x * (uint64_t)div_y;
     if (M < (uint64_t)N || M > 0xFFFFFFFFull) return -2;
@@ -361,7 +362,7 @@ int oracle_reset(int N, int div_x, int div_y, double pitch, uint64_t seed, uint6
     int32_t *cand = (int32_t *)malloc(sizeof(int32_t) * N);
     uint8_t *win = (uint8_t *)malloc((size_t)N);
     if (!node || !cand || !win) return -1;
-    const uint32_t k0 = (uint32_t)seed ^ (uint32_t)(counter >> 32), k1 = (uint32_t)(seed >> 32);
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     int rc = 0;
     for (int e = 0; e < E && rc == 0; ++e) {
         if (mask && !mask[e]) continue;
@@ -372,7 +373,7 @@ int oracle_reset(int N, int div_x, int div_y, double pitch, uint64_t seed, uint6
             if (r >= (1u << 20)) { rc = -3; break; }
             for (int i = 0; i < N; ++i) {
                 if (node[i] >= 0) continue;
-                const uint32_t w = oracle_philox_word0((uint32_t)i, r, gid, (uint32_t)counter, k0, k1);
+                const uint32_t w = oracle_philox_word0((uint32_t)i, r, gid, (uint32_t)episode[e], k0, k1);
                 cand[i] = (int32_t)(((uint64_t)w * M) >> 32);
             }
             /* decide against the state at the START of the round (as the parallel kernel
@@ -402,6 +403,7 @@ int oracle_reset(int N, int div_x, int div_y, double pitch, uint64_t seed, uint6
             if (node_out) node_out[(size_t)e * N + i] = node[i];
         }
         t[e] = 0;                                                         /* :100 */
+        episode[e] += 1;
     }
     free(node); free(cand); free(win);
     return rc;

@@ -1,0 +1,11 @@
+"""MI355X-native batched drone_env hot path (step / reset / get_local_states).
+
+Drop-in for `/root/reference/drone_env.py` class `drones`; see drone_env.py in this
+package, include/dronesim.h (C ABI) and csrc/dronesim.hip (gfx950 kernels).
+Importing the package needs neither a GPU nor the built library; constructing an
+environment needs both (no CPU fallback)."""
+from .drone_env import (DroneState, StepResult, clip_deltas, dim, drones, dt, formation_O,
+                        lattice_divisions, max_time_steps, shard_range)
+
+__all__ = ["drones", "DroneState", "StepResult", "dim", "dt", "max_time_steps", "formation_O",
+           "clip_deltas", "lattice_divisions", "shard_range"]

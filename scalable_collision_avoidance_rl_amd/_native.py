@@ -1,0 +1,78 @@
+"""ctypes binding of the C ABI in include/dronesim.h (libdronesim.so, HIP/gfx950).
+
+There is NO CPU fallback: if the library is missing, import of this module's
+`lib()` fails loudly with build instructions.  All pointers handed to the
+library are raw device addresses (`tensor.data_ptr()`); PyTorch only provides
+the memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+# DRONESIM_LIB lets a developer A/B an alternative build of the SAME HIP library (no other backend exists)
+LIB_PATH = os.environ.get("DRONESIM_LIB") or os.path.join(_PKG, "libdronesim.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dronesim.h")
+
+OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
+MAX_K = 8
+MAX_AGENTS = 1024
+
+# every symbol include/dronesim.h declares (tests check the .so exports all of them)
+SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout",
+           "dronesim_last_error", "dronesim_error_string", "dronesim_version")
+
+
+class DroneParams(C.Structure):
+    """Mirror of `struct DroneParams` (include/dronesim.h)."""
+    _fields_ = [("N", C.c_int32), ("k", C.c_int32), ("c", C.c_int32), ("max_steps", C.c_int32),
+                ("dt", C.c_float), ("q", C.c_float), ("b", C.c_float),
+                ("done_radius", C.c_float), ("ghost_factor", C.c_float),
+                ("d_hat_min", C.c_float), ("delta_max", C.c_float), ("radius_max", C.c_float),
+                ("xF", C.c_void_p), ("d_hat", C.c_void_p), ("delta", C.c_void_p),
+                ("radius", C.c_void_p)]
+
+
+class DroneSimError(RuntimeError):
+    def __init__(self, code, where, detail):
+        super().__init__(f"{where} failed with code {code}: {detail}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libdronesim.so (built by __graft_entry__.build() / `make -C <pkg>/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+            "scalable_collision_avoidance_rl_amd/csrc`) with hipcc for gfx950. "
+            "There is no CPU fallback for this path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, u64, i64, f32 = C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_float
+    P = C.POINTER(DroneParams)
+    L.dronesim_step.argtypes = [P] + [vp] * 10 + [i32, vp]
+    L.dronesim_observe.argtypes = [P] + [vp] * 8 + [i32, vp]
+    L.dronesim_rollout.argtypes = [P] + [vp] * 10 + [i32, i32, vp]
+    L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
+    for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset",
+                 "dronesim_version"):
+        getattr(L, name).restype = C.c_int
+    L.dronesim_last_error.restype = C.c_char_p
+    L.dronesim_error_string.restype = C.c_char_p
+    L.dronesim_error_string.argtypes = [C.c_int]
+    _lib = L
+    return L
+
+
+def check(rc, where):
+    if rc != OK:
+        L = lib()
+        raise DroneSimError(rc, where, f"{L.dronesim_error_string(rc).decode()} -- "
+                                       f"{L.dronesim_last_error().decode()}")

@@ -1,0 +1,419 @@
+"""MI355X-native batched `drones` environment: drop-in for the reference class.
+
+Host-side mirror of `/root/reference/drone_env.py:53-401` (class `drones`) for the
+step()/reset()/get_local_states() hot path.  Everything per-timestep runs in the
+hand-written HIP kernels of csrc/dronesim.hip through the C ABI of
+include/dronesim.h; this file only owns the caller-facing surface:
+
+* construction-time constants (goal ring, safety distance, Delta clip) computed once
+  on the host exactly as the reference does (drone_env.py:83-91, 115-153),
+* device buffers (torch tensors = HBM allocations) and the current HIP stream,
+* the two faces of the API:
+    - ``n_envs == 1`` (default): the reference's own Python types -- ``state`` a live
+      ``[N,5]`` float64 ndarray, ``z_states`` a list of ``[k+1,c]`` ndarrays, ``Ni`` a
+      list of int lists, ``step()`` returning the reference 6-tuple
+      (drone_env.py:258) -- so `SAC_agents.py` / `train_problem.py:82-107` loops run
+      unchanged;
+    - ``n_envs > 1``: the same method names on ``[E, ...]`` device tensors with no
+      host synchronisation per step.
+
+There is no CPU fallback: constructing an env without the built HIP library or
+without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+# module constants of the reference (drone_env.py:27-30)
+dim = 2
+dt = 0.05
+max_time_steps = 200
+
+DRONE_RADIUS = 0.1          # drone_env.py:75, 174
+DONE_RADIUS = 0.2           # drone_env.py:251
+GHOST_FACTOR = 1.1          # drone_env.py:386
+LATTICE_PITCH = 2 * 1.1 * DRONE_RADIUS   # drone_env.py:193
+
+
+# --------------------------------------------------------------------------------------
+# host-side, once-per-env precompute (pure NumPy; testable without a GPU)
+
+def formation_O(n_agents: int, grid, drone_radius=None):
+    """Goal ring and safety distance of end_formation == "O" (drone_env.py:124-153).
+
+    Returns ``(end_points [2N,1] column, d_safety [N])`` in float64 like the reference."""
+    n = int(n_agents)
+    gx, gy = float(grid[0]), float(grid[1])
+    radius = np.full(n, DRONE_RADIUS) if drone_radius is None else np.asarray(drone_radius, np.float64)
+    ang = np.arange(n) * (2 * np.pi / n)
+    xF = np.stack([np.cos(ang) * 0.9 * gx / 2 + gx / 2, np.sin(ang) * 0.9 * gy / 2 + gy / 2], axis=1)
+    diff = xF[:, None, :] - xF[None, :, :]
+    gap = np.sqrt((diff ** 2).sum(-1)) - radius[:, None] - radius[None, :]
+    np.fill_diagonal(gap, np.inf)
+    d_safety = np.floor(gap.min(axis=1) * 100) / 100
+    return xF.reshape(2 * n, 1), d_safety
+
+
+def clip_deltas(deltas, d_safety, warn=True):
+    """deltas=None -> d_safety; else min(deltas, d_safety) with the reference's warning (drone_env.py:85-91)."""
+    if deltas is None:
+        return d_safety
+    deltas = np.asarray(deltas, np.float64)
+    out = np.minimum(deltas, d_safety)
+    if warn and not np.all(deltas <= d_safety):
+        print("Some deltas are greater than the final minimum distance between end positions. Using minimum "
+              "distance between end positions for those cases instead.", f"deltas = {out}")
+    return out
+
+
+def lattice_divisions(grid):
+    """Nodes per axis of the initial-position lattice (drone_env.py:193-194)."""
+    d = np.floor(np.array(grid, np.float64) / LATTICE_PITCH)
+    return int(d[0]), int(d[1])
+
+
+def shard_range(n_envs: int, rank: int, world_size: int):
+    """Contiguous slice [lo, hi) of the env axis owned by `rank` (envs never interact)."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    base, rem = divmod(int(n_envs), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+StepResult = namedtuple("StepResult", "state z_states rewards n_collisions finished true_rewards")
+
+
+class DroneState:
+    """Batched state view: ``pos``/``vel`` ``[E,N,2]`` device tensors (live), ``radius`` ``[N]``."""
+    __slots__ = ("pos", "vel", "radius")
+
+    def __init__(self, pos, vel, radius):
+        self.pos, self.vel, self.radius = pos, vel, radius
+
+    def tensor(self):
+        """``[E,N,5]`` copy in the reference's column order x, y, vx, vy, l (drone_env.py:173)."""
+        import torch
+        E, N = self.pos.shape[:2]
+        return torch.cat([self.pos, self.vel, self.radius.view(1, N, 1).expand(E, N, 1)], dim=2)
+
+    def copy(self):
+        return self.tensor()
+
+
+class drones:
+    """Batched multi-agent 2-D formation / collision-avoidance environment on MI355X.
+
+    Signature and attributes follow the reference (drone_env.py:55); keyword-only
+    additions: ``n_envs`` (E parallel, independent envs), ``device``, ``seed``,
+    ``rank``/``world_size`` (shard the env axis across one-process-per-GPU ranks),
+    ``batched`` (force tensor API at E == 1)."""
+
+    def __init__(self, n_agents: int, n_obstacles: int, grid: list, end_formation: str, k_closest=2,
+                 deltas: np.ndarray = None, simplify_zstate=False, *, n_envs: int = 1, device=None,
+                 seed: int = None, rank: int = 0, world_size: int = 1, batched: bool = None) -> None:
+        import torch
+        from . import _native
+
+        self._torch = torch
+        self._native = _native
+        self._lib = _native.lib()                     # raises ImportError if the HIP library is missing
+        if not torch.cuda.is_available():
+            raise RuntimeError("scalable_collision_avoidance_rl_amd.drones needs a ROCm GPU (MI355X); "
+                               "there is no CPU fallback for the step()/reset() path")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError(f"device must be a ROCm GPU, got {self.device}")
+
+        self.n_agents = int(n_agents)
+        self.grid = grid
+        self.goal = self.grid
+        self.k_closest = int(k_closest)
+        self.simplify_zstate = bool(simplify_zstate)
+        self.internal_t = 0
+        self.collision_weight = 0.2                   # live attribute, read at every step (drone_env.py:72, 270)
+        self.drone_radius = np.ones(self.n_agents) * DRONE_RADIUS
+        self.A = np.eye(dim)
+        self.B = np.eye(dim) * dt
+
+        N, k = self.n_agents, self.k_closest
+        if N < 2 or N > _native.MAX_AGENTS:
+            raise ValueError(f"n_agents must be in 2..{_native.MAX_AGENTS}")
+        if not (1 <= k <= min(N - 1, _native.MAX_K)):
+            raise ValueError(f"k_closest must be in 1..min(n_agents-1, {_native.MAX_K}) "
+                             "(the reference raises IndexError for k_closest >= n_agents)")
+        if end_formation != "O":
+            raise ValueError(str(end_formation) + " is Not a valid end formation identifier")
+
+        self.obstacles = self.create_obstacles(n_obstacles)
+        self.end_points, self.d_safety = formation_O(N, grid, self.drone_radius)
+        if not np.all(self.d_safety > 0):
+            raise ValueError(f"safety distance d_hat = {self.d_safety.min():.2f} <= 0: the goal ring does not fit "
+                             f"{N} agents on grid {grid} (need 0.9*G*sin(pi/N) > 0.2); the reference's reward is "
+                             "degenerate there")
+        self.deltas = clip_deltas(deltas, self.d_safety)
+
+        # sharding of the env axis
+        self.n_envs_global = int(n_envs)
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.env_lo, self.env_hi = shard_range(self.n_envs_global, self.rank, self.world_size)
+        self.n_envs = self.env_hi - self.env_lo
+        if self.n_envs < 1:
+            raise ValueError("this rank owns no environments")
+        self.batched = (self.n_envs_global > 1) if batched is None else bool(batched)
+        self.seed = int(np.random.SeedSequence().entropy & 0xFFFFFFFFFFFFFFFF) if seed is None else int(seed)
+
+        self.global_state_space = N * (2 * dim + 1)
+        self.c = dim if self.simplify_zstate else 2 * dim + 1
+        self.local_state_space = self.c * (1 + k)     # drone_env.py:180-184
+        self.global_action_space = N * dim
+        self.local_action_space = dim
+
+        self._alloc()
+        self.reset(renew_obstacles=False)
+
+    # ------------------------------------------------------------------ buffers / params
+    def _alloc(self):
+        torch = self._torch
+        E, N, K1, c = self.n_envs, self.n_agents, self.k_closest + 1, self.c
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._xF = torch.tensor(self.end_points.reshape(N, 2), **f32).contiguous()
+        self._d_hat = torch.tensor(self.d_safety, **f32)
+        self._delta = torch.tensor(np.asarray(self.deltas, np.float64), **f32)
+        self._radius = torch.tensor(self.drone_radius, **f32)
+        self.pos = torch.zeros(E, N, 2, **f32)
+        self.vel = torch.zeros(E, N, 2, **f32)
+        self.t = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.episode = torch.zeros(E, dtype=torch.int32, device=dev)   # resets seen per env (RNG stream id)
+        # per-step outputs (overwritten by every step) and current observation
+        self.reward = torch.zeros(E, N, **f32)
+        self.true_reward = torch.zeros(E, N, **f32)
+        self.z = torch.zeros(E, N, K1 * c, **f32)
+        self.nbr_idx = torch.full((E, N, K1), -1, dtype=torch.int32, device=dev)
+        self.n_coll = torch.zeros(E, dtype=torch.int32, device=dev)
+        self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
+        self._act = torch.zeros(E, N, 2, **f32)
+        self._params_cache = None
+        self.state = DroneState(self.pos, self.vel, self._radius) if self.batched else None
+
+    def _params(self):
+        """DroneParams for this launch (collision_weight is live: train_problem.py:31)."""
+        P = self._native.DroneParams
+        key = float(self.collision_weight)
+        if self._params_cache is None or self._params_cache[0] != key:
+            p = P()
+            p.N, p.k, p.c, p.max_steps = self.n_agents, self.k_closest, self.c, max_time_steps
+            p.dt, p.q, p.b = dt, 2 * dt, key * dt                      # drone_env.py:269-270
+            p.done_radius, p.ghost_factor = DONE_RADIUS, GHOST_FACTOR
+            # float32 images of the arrays (what the kernel compares) bound the variant choice
+            p.d_hat_min = float(self._d_hat.min().item())
+            p.delta_max = float(self._delta.max().item())
+            p.radius_max = float(self._radius.max().item())
+            p.xF, p.d_hat = self._xF.data_ptr(), self._d_hat.data_ptr()
+            p.delta, p.radius = self._delta.data_ptr(), self._radius.data_ptr()
+            self._params_cache = (key, p)
+        return self._params_cache[1]
+
+    def _stream(self):
+        return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ------------------------------------------------------------------ reference API
+    def create_obstacles(self, n_obstacles):
+        """Cosmetic obstacles (never read by dynamics or reward) -- drone_env.py:155-169."""
+        self.n_obstacles = n_obstacles
+        max_size = 0.1 * np.max(self.grid)
+        min_size = 0.05 * max_size
+        obstacles = np.random.rand(n_obstacles, dim + 1)
+        obstacles[:, 0] *= self.grid[0]
+        obstacles[:, 1] *= self.grid[1]
+        obstacles[:, dim] = obstacles[:, dim] * (max_size - min_size) + min_size
+        return obstacles
+
+    def reset(self, renew_obstacles=True, mask=None):
+        """Re-sample initial states on the lattice, zero t, refresh z / Ni (drone_env.py:98-102, 171-212).
+
+        ``mask`` (bool/uint8 ``[E]`` device tensor, batched mode) resets only the flagged envs."""
+        torch = self._torch
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        dx, dy = lattice_divisions(self.grid)
+        p = self._params()
+        with torch.cuda.device(self.device):
+            rc = self._lib.dronesim_reset(C.byref(p), dx, dy, float(LATTICE_PITCH), self.seed,
+                                          self.env_lo, None if m is None else m.data_ptr(),
+                                          self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
+                                          self.episode.data_ptr(), None, self.n_envs, self._stream())
+            self._native.check(rc, "dronesim_reset")
+            self._observe(m)
+        if m is None:
+            self.internal_t = 0
+        if renew_obstacles:
+            self.obstacles = self.create_obstacles(self.n_obstacles)
+        self._sync_host_views()
+
+    def _observe(self, mask=None, rewards=False):
+        p = self._params()
+        rc = self._lib.dronesim_observe(C.byref(p), self.pos.data_ptr(), self.vel.data_ptr(),
+                                        self.reward.data_ptr() if rewards else None,
+                                        self.true_reward.data_ptr() if rewards else None,
+                                        self.z.data_ptr(), self.nbr_idx.data_ptr(),
+                                        self.n_coll.data_ptr() if rewards else None,
+                                        None if mask is None else mask.data_ptr(), self.n_envs, self._stream())
+        self._native.check(rc, "dronesim_observe")
+
+    def step(self, actions):
+        """One env.step() for every env (drone_env.py:214-258).
+
+        Compat mode (E == 1): ``actions`` is any indexable of N array-likes ``[2]`` (list or deque);
+        returns ``(state, z_states, r_vec, n_collisions, finished, true_r_vec)`` in the reference's
+        types.  Batched mode: ``actions`` is a ``[E,N,2]`` float32 tensor on this env's device;
+        returns a `StepResult` of device tensors (no host sync)."""
+        torch = self._torch
+        if self.batched:
+            act = actions
+            if not (torch.is_tensor(act) and act.dtype == torch.float32 and act.device == self.device
+                    and act.is_contiguous()):
+                act = torch.as_tensor(np.asarray(act, np.float32) if not torch.is_tensor(act) else act,
+                                      dtype=torch.float32, device=self.device).contiguous()
+            if tuple(act.shape) != (self.n_envs, self.n_agents, 2):
+                raise ValueError(f"actions must be [{self.n_envs},{self.n_agents},2], got {tuple(act.shape)}")
+        else:
+            self._push_host_state()
+            a = np.asarray([np.asarray(actions[i], np.float64).reshape(2) for i in range(self.n_agents)],
+                           np.float32)
+            self._act.copy_(torch.from_numpy(a).view(1, self.n_agents, 2), non_blocking=False)
+            act = self._act
+        p = self._params()
+        with torch.cuda.device(self.device):
+            rc = self._lib.dronesim_step(C.byref(p), self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
+                                         act.data_ptr(), self.reward.data_ptr(), self.true_reward.data_ptr(),
+                                         self.z.data_ptr(), self.nbr_idx.data_ptr(), self.n_coll.data_ptr(),
+                                         self.done.data_ptr(), self.n_envs, self._stream())
+        self._native.check(rc, "dronesim_step")
+        if self.batched:
+            return StepResult(DroneState(self.pos, self.vel, self._radius), self.z, self.reward, self.n_coll,
+                              self.done, self.true_reward)
+        self._sync_host_views()
+        r = self.reward[0].double().cpu().numpy()
+        tr = self.true_reward[0].double().cpu().numpy()
+        n_coll = np.int64(self.n_coll[0].item())
+        finished = bool(self.done[0].item())
+        self.internal_t += 1
+        return self.state, self.z_states, r, n_coll, finished, tr
+
+    def rollout(self, actions):
+        """T fused steps in one launch with the actions known up front (RandomAgent-style rollouts,
+        SAC_agents.py:9-22 + train_problem.py:82-107).  ``actions``: ``[T,E,N,2]`` float32 device tensor.
+        Returns a dict of ``[T, ...]`` tensors with every per-step output of step()."""
+        torch = self._torch
+        E, N, K1, c = self.n_envs, self.n_agents, self.k_closest + 1, self.c
+        act = actions.to(device=self.device, dtype=torch.float32).contiguous()
+        T = act.shape[0]
+        if tuple(act.shape) != (T, E, N, 2):
+            raise ValueError(f"actions must be [T,{E},{N},2], got {tuple(act.shape)}")
+        f32 = dict(dtype=torch.float32, device=self.device)
+        out = dict(reward=torch.empty(T, E, N, **f32), true_reward=torch.empty(T, E, N, **f32),
+                   z=torch.empty(T, E, N, K1 * c, **f32),
+                   nbr_idx=torch.empty(T, E, N, K1, dtype=torch.int32, device=self.device),
+                   n_coll=torch.empty(T, E, dtype=torch.int32, device=self.device),
+                   done=torch.empty(T, E, dtype=torch.uint8, device=self.device))
+        if not self.batched:
+            self._push_host_state()
+        p = self._params()
+        with torch.cuda.device(self.device):
+            rc = self._lib.dronesim_rollout(C.byref(p), self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
+                                            act.data_ptr(), out["reward"].data_ptr(), out["true_reward"].data_ptr(),
+                                            out["z"].data_ptr(), out["nbr_idx"].data_ptr(), out["n_coll"].data_ptr(),
+                                            out["done"].data_ptr(), E, T, self._stream())
+        self._native.check(rc, "dronesim_rollout")
+        if T > 0:
+            self.z.copy_(out["z"][-1]); self.nbr_idx.copy_(out["nbr_idx"][-1])
+            self.reward.copy_(out["reward"][-1]); self.true_reward.copy_(out["true_reward"][-1])
+            self.n_coll.copy_(out["n_coll"][-1]); self.done.copy_(out["done"][-1])
+        if not self.batched:
+            self.internal_t += T
+            self._sync_host_views()
+        return out
+
+    def get_local_states(self):
+        """Current localized observation.  Compat: ``(z_states, Ni)`` (the attributes
+        train_problem.py:85-86 reads).  Batched: ``(z [E,N,(k+1)c], nbr_idx [E,N,k+1], nbr_cnt [E,N])``
+        with ``nbr_cnt = len(Ni[i])`` (1..k+1)."""
+        if not self.batched:
+            return self.z_states, self.Ni
+        return self.z, self.nbr_idx, (self.nbr_idx >= 0).sum(dim=2, dtype=self._torch.int32)
+
+    # ------------------------------------------------------------------ state injection / checkpoint
+    def set_state(self, pos, vel=None, t=None):
+        """Inject a state (parity tests, checkpoints) and refresh the observation (rewards() path)."""
+        torch = self._torch
+        E, N = self.n_envs, self.n_agents
+        self.pos.copy_(torch.as_tensor(np.asarray(pos, np.float32) if not torch.is_tensor(pos) else pos,
+                                       dtype=torch.float32).reshape(E, N, 2))
+        if vel is None:
+            self.vel.zero_()
+        else:
+            self.vel.copy_(torch.as_tensor(np.asarray(vel, np.float32) if not torch.is_tensor(vel) else vel,
+                                           dtype=torch.float32).reshape(E, N, 2))
+        if t is not None:
+            tt = torch.as_tensor(np.asarray(t, np.int32) if not torch.is_tensor(t) else t, dtype=torch.int32)
+            self.t.copy_(tt.reshape(-1).expand(E) if tt.numel() == 1 else tt.reshape(E))
+            if not self.batched:
+                self.internal_t = int(self.t[0].item())
+        with torch.cuda.device(self.device):
+            self._observe(rewards=True)
+        self._sync_host_views()
+
+    def get_state(self):
+        """``dict(pos, vel, t, episode, seed)`` clones -- everything needed to resume the env."""
+        return dict(pos=self.pos.clone(), vel=self.vel.clone(), t=self.t.clone(),
+                    episode=self.episode.clone(), seed=self.seed)
+
+    # ------------------------------------------------------------------ compat-mode host views
+    def _sync_host_views(self):
+        """E == 1 compat: mirror device state/observation into the reference's Python types."""
+        if self.batched:
+            return
+        N, K1, c = self.n_agents, self.k_closest + 1, self.c
+        st = np.empty((N, 5))
+        st[:, 0:2] = self.pos[0].double().cpu().numpy()
+        st[:, 2:4] = self.vel[0].double().cpu().numpy()
+        st[:, 4] = self.drone_radius
+        if getattr(self, "state", None) is None or self.state.shape != st.shape:
+            self.state = st
+        else:
+            self.state[...] = st                      # keep the same live array object (drone_env.py:258)
+        self._state_pushed = self.state.copy()
+        z = self.z[0].double().cpu().numpy().reshape(N, K1, c)
+        nb = self.nbr_idx[0].cpu().numpy()
+        self.z_states = [z[i].copy() for i in range(N)]
+        self.Ni = [[int(i)] + [np.int64(j) for j in nb[i, 1:] if j >= 0] for i in range(N)]
+
+    def _push_host_state(self):
+        """Callers may write into env.state / env.internal_t between steps (the reference's state is a
+        plain attribute); upload it if it changed."""
+        torch = self._torch
+        if self.batched:
+            return
+        if not np.array_equal(self.state[:, :4], self._state_pushed[:, :4]):
+            self.pos.copy_(torch.from_numpy(self.state[None, :, 0:2].astype(np.float32)))
+            self.vel.copy_(torch.from_numpy(self.state[None, :, 2:4].astype(np.float32)))
+        self.t.fill_(int(self.internal_t))
+
+    def __str__(self):
+        """Same printout as the reference (drone_env.py:105-113); returns ""."""
+        print("Grid size: [x_lim, y_lim]\n", self.grid)
+        if self.batched:
+            print(f"State: {self.n_envs} envs x {self.n_agents} agents on {self.device} (pos/vel tensors)")
+        else:
+            print("State: [x, y, vx, vy, r]\n", self.state)
+        print(f"z_sattes for k_closest = {self.k_closest}: simplify? {self.simplify_zstate}")
+        print("safety distance for each agent:\n", self.d_safety)
+        print("Deltas disk radius for each agent: \n", self.deltas)
+        print(f"Collision cost weight (per unit of time) = {self.collision_weight} ")
+        return ""

@@ -88,8 +88,15 @@ def analyse(env, state):
     return m, tie_free, selection_tied
 
 
+def f32_exact(a):
+    """Round inputs to float32-representable float64 values: the reference (float64 arithmetic) and the
+    float32 HIP path then start from IDENTICAL inputs."""
+    return np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+
+
 def run_case(env, pos, vel, t, act):
     N, k = env.n_agents, env.k_closest
+    pos, vel, act = f32_exact(pos), f32_exact(vel), f32_exact(act)
     env.state[:, 0:2] = pos
     env.state[:, 2:4] = vel
     env.internal_t = int(t)

@@ -11,6 +11,16 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # fp32 parity bar of BASELINE.md section 4 / north_star: |a-b| <= 1e-5 * max(1, |ref|)
 RTOL = 1e-5
 ATOL = 1e-5
+
+
+def atol_coord(G):
+    """Absolute tolerance for outputs that are DIFFERENCES OF COORDINATES (z rows: x_j - x_i, x_i - xF_i).
+    The state is stored in float32, so each coordinate of magnitude <= G carries up to half an ulp32(G) of
+    rounding after the integrator and the difference up to one ulp32(G) -- 4.8e-7 at G=5, 1.9e-6 at G=28 but
+    3.1e-5 at G=256, above a flat 1e-5.  The bar is therefore 1e-5 + ulp32(G)."""
+    return ATOL + float(np.spacing(np.float32(G)))
+
+
 # discrete outputs (n_coll, done, neighbour ids) are compared exactly where every
 # decision is at least this far from its threshold (SURVEY.md 7.3-1)
 MARGIN = 1e-4
