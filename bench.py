@@ -40,12 +40,32 @@ WORKLOADS = {
 }
 
 
+def pmc_traffic(workload):
+    """HBM-side bytes per step launch from the latest committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of this workload (tools/pmc_run.py + tools/pmc_parse.py; counters cannot be read from inside
+    the benchmarked process).  None when no such profile is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(N, G, delta, budget_s=12.0):
     """Oracle (C port of the reference path) timed on this host: a bounded sample of the same workload."""
     from oracle.oracle import Oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                            # honour a cgroup CPU quota if the box sets one
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     orc = Oracle(N, [G, G], 2, np.ones(N) * delta, True, threads=cores)
-    E = max(cores * 8, 64)
+    E = max(cores * 16, 64)
     pos, vel, t, _, _ = orc.reset(E, 1234)
     rng = np.random.default_rng(0)
     act = rng.uniform(-1, 1, (E, N, 2))
@@ -76,6 +96,7 @@ def main():
     import torch
     import torch.distributed as dist
     from scalable_collision_avoidance_rl_amd import drones, max_time_steps
+    from scalable_collision_avoidance_rl_amd.sharding import EpisodeStats
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,13 +119,12 @@ def main():
     # synthetic actions, resident in HBM: one episode's worth, reused every episode
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = torch.rand(T_ep, E, N, 2, device=dev, generator=g) * 2 - 1
-    stats = torch.zeros(4, dtype=torch.float64, device=dev)     # sum r, sum true r, collisions, env-steps
+    stats = EpisodeStats(dev)                       # what train_problem.py:98-100 logs, kept on device
 
     def one_step(s):
         res = env.step(pool[s % T_ep])
-        if (s + 1) % T_ep == 0:                     # episode end: log the global statistic, reset
-            stats[0] += res.rewards.sum(); stats[1] += res.true_rewards.sum()
-            stats[2] += res.n_collisions.sum(); stats[3] += E
+        if (s + 1) % T_ep == 0:                     # episode end: sample the statistic, reset (train_problem.py:132)
+            stats.add_step(res.rewards, res.true_rewards, res.n_collisions)
             env.reset(renew_obstacles=False)
 
     def barrier():
@@ -127,7 +147,6 @@ def main():
             for s in range(T_ep):                   # every replayed reset draws fresh initial states
                 one_step(s)
 
-    ev = []                                          # HIP events around sampled launches (same stream)
     barrier()
     t0 = time.perf_counter()
     done = 0
@@ -135,30 +154,35 @@ def main():
         while done + T_ep <= args.steps:
             graph.replay(); done += T_ep
     while done < args.steps:
-        if done % 8 == 0 and graph is None:
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); one_step(step_no); b.record(); ev.append((a, b))
-        else:
-            one_step(step_no)
+        one_step(step_no)
         step_no += 1; done += 1
     barrier()
     elapsed = time.perf_counter() - t0
 
-    # kernel duration: HIP events around single step launches on the launch stream
-    if not ev:
-        for s in range(64):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); env.step(pool[s]); b.record(); ev.append((a, b))
-        torch.cuda.synchronize()
-    kern_ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    # Duration of the dominant kernel (drone_kernel<step>) per launch, by HIP events on the launch stream
+    # (torch's current stream = the stream handed to dronesim_step): events bracket a hipGraph holding
+    # ONLY `n_samp` back-to-back step launches, so (t1 - t0) / n_samp is the kernel's duration including the
+    # ~0.2 us dependent-launch boundary and excluding host launch latency.  rocprofv3 --kernel-trace --stats
+    # of this command reports the same kernel's average duration (profiles/).
+    n_samp = T_ep
+    kgraph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(kgraph):
+        for s in range(n_samp):
+            env.step(pool[s])
+    kgraph.replay(); torch.cuda.synchronize()
+    samples = []
+    for _ in range(10):
+        env.reset(renew_obstacles=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); kgraph.replay(); e1.record(); torch.cuda.synchronize()
+        samples.append(e0.elapsed_time(e1) / n_samp)
+    kern_ms = float(np.median(samples))
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        # the path's only exchange: the global reward statistic (train_problem.py:98-100, 118-120)
-        gathered = torch.empty(world, 4, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(gathered, stats.view(1, 4))
-        stats = gathered.sum(0)
+    # the path's only exchange: all-gather of the global reward statistic (RCCL over xGMI when world > 1)
+    summary = stats.reduce()
     elapsed = float(el.item())
 
     if rank == 0:
@@ -166,6 +190,7 @@ def main():
         value = agent_steps / elapsed
         bytes_launch = BYTES_PER_AGENT_STEP * N * E + BYTES_PER_ENV_STEP * E
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(args.workload) if e_gpu == WORKLOADS[args.workload][1] else (None, None)
         out = {
             "metric": "env agent-steps/sec (n_agents x n_envs x steps)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -176,12 +201,10 @@ def main():
                        "launch": "hipGraph replay (200 steps + reset per graph)" if graph is not None else "eager",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "drone_kernel<K=2,FAR=0,step>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
-            "episode_stats": {"mean_reward": float(stats[0] / max(float(stats[3]) * N, 1)),
-                              "mean_true_reward": float(stats[1] / max(float(stats[3]) * N, 1)),
-                              "collisions_per_env_at_episode_end": float(stats[2] / max(float(stats[3]), 1))},
+            "episode_end_stats": summary,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, G, delta, args.cpu_budget)

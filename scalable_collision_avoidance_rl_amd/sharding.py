@@ -1,0 +1,57 @@
+"""Multi-GPU layout of the hot path: shard the env axis, exchange only the logged statistic.
+
+Environments never interact (one `drones` object = one env in the reference), so rank g of W
+owns envs [lo, hi) of the global env axis (`shard_range`) and steps them with no data-path
+collective.  The only exchange is the global reward / collision statistic the rollout loop
+logs per episode (train_problem.py:98-100, 118-120): each rank contributes one small float64
+vector; one all-gather (RCCL over xGMI when the backend is "nccl", gloo in the CPU tests)
+per episode -- or per K steps -- makes the global figures available on every rank.  The
+message is tens of bytes: latency-bound, kept off the per-step path."""
+from __future__ import annotations
+
+from .drone_env import shard_range  # noqa: F401  (re-exported)
+
+STAT_FIELDS = ("sum_reward", "sum_true_reward", "sum_collisions", "agent_steps", "env_steps")
+
+
+class EpisodeStats:
+    """Per-rank accumulators of the logged statistic, kept on the env's device (no host sync)."""
+
+    def __init__(self, device):
+        import torch
+        self.vec = torch.zeros(len(STAT_FIELDS), dtype=torch.float64, device=device)
+
+    def add_step(self, rewards, true_rewards, n_collisions):
+        """rewards/true_rewards [E,N], n_collisions [E] of one step (what train_problem.py:98-100 sums)."""
+        E, N = rewards.shape
+        self.vec[0] += rewards.sum(dtype=self.vec.dtype)
+        self.vec[1] += true_rewards.sum(dtype=self.vec.dtype)
+        self.vec[2] += n_collisions.sum(dtype=self.vec.dtype)
+        self.vec[3] += E * N
+        self.vec[4] += E
+
+    def reduce(self, group=None):
+        """All-gather every rank's vector and sum locally -> dict of global figures (same on all ranks)."""
+        return summarize(all_gather_stats(self.vec, group))
+
+
+def all_gather_stats(vec, group=None):
+    """[world, len(vec)] tensor holding every rank's statistic vector (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return vec.view(1, -1).clone()
+    world = dist.get_world_size(group)
+    out = torch.empty(world, vec.numel(), dtype=vec.dtype, device=vec.device)
+    dist.all_gather_into_tensor(out, vec.view(1, -1).contiguous(), group=group)
+    return out
+
+
+def summarize(gathered):
+    """Global means from the gathered [world, 5] statistic."""
+    tot = gathered.sum(0)
+    agent_steps = max(float(tot[3]), 1.0)
+    env_steps = max(float(tot[4]), 1.0)
+    return {"mean_reward": float(tot[0]) / agent_steps, "mean_true_reward": float(tot[1]) / agent_steps,
+            "collisions_per_env_step": float(tot[2]) / env_steps, "agent_steps": float(tot[3]),
+            "env_steps": float(tot[4]), "world_size": int(gathered.shape[0])}
