@@ -65,8 +65,9 @@ typedef struct DroneParams {
     float ghost_factor;     /* 1.1                                                  */
     /* host-known bounds of the arrays below (the library never reads device
        memory on the host): used to pick the kernel variant and the early-out
-       radius.  d_hat_min must be > 0.                                              */
+       radius.  0 < d_hat_min <= d_hat_max required.                                */
     float d_hat_min;
+    float d_hat_max;
     float delta_max;
     float radius_max;
     const float *xF;        /* [N][2] */

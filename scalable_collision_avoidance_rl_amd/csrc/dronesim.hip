@@ -48,10 +48,17 @@ constexpr float kLn2 = 0.693147180559945309f;
 
 enum Mode { kStep = 0, kObserve = 1, kRollout = 2 };
 
+#if defined(DRONESIM_TRACE)
+#define TRACE_MARK(k) do { if (a.trace && (threadIdx.x & 63) == 0) a.trace[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TRACE_MARK(k) do {} while (0)
+#endif
+
 struct KArgs {
+    long long *trace;               // developer builds (-DDRONESIM_TRACE) only: per-wave phase timestamps
     int N, c, max_steps, E, T;
     int P, epb;                     // envs per wave (0 when N > 64), envs per workgroup
-    float dt, q, b, done_radius, ghost_factor, radius_max;
+    float dt, q, b, done_radius, ghost_factor, radius_max, reach_max;
     const float *xF, *d_hat, *delta, *radius;
     float *pos, *vel;
     int *t;
@@ -90,23 +97,81 @@ __device__ __forceinline__ float nan_to_num_f32(float x)   // np.nan_to_num, dro
     return fminf(fmaxf(x, -3.402823466e+38f), 3.402823466e+38f);
 }
 
-template <int K, bool FAR, int MODE, int MAXT>
-__global__ void __launch_bounds__(MAXT) drone_kernel(const KArgs a)
+// Output stores.  The outputs of a step are never re-read by the launch that writes them, so they are
+// written with the non-temporal (streaming) policy: lines drain to memory while the kernel runs instead
+// of sitting dirty in the XCD L2 until the end-of-kernel write-back.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#if defined(DRONESIM_PLAIN_STORES)
+template <typename T> __device__ __forceinline__ void st_out(T *p, T v) { *p = v; }
+#else
+template <typename T> __device__ __forceinline__ void st_out(T *p, T v) { __builtin_nontemporal_store(v, p); }
+#endif
+__device__ __forceinline__ void st_out2(float *p, float x, float y)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = a.N;
-    const int stride = 2 * N + kPad;                         // float2 per env slot
-    float2 *spos = reinterpret_cast<float2 *>(smem);                                       // [epb][stride]
-    float2 *sconst = spos + (size_t)a.epb * stride;                                        // [N] (Delta_j, l_j)
-    int *sred = reinterpret_cast<int *>(sconst + N);                                       // [epb][2]
+    f32x2 v; v.x = x; v.y = y;
+    st_out(reinterpret_cast<f32x2 *>(p), v);
+}
 
+// Cooperative copy of `n` 4-byte words from a wave's LDS staging area to global memory: 16 bytes per
+// lane when the destination is 16-byte aligned (full 128-B lines, 1 KiB per wave-instruction),
+// 4 bytes per lane otherwise.
+__device__ __forceinline__ void wave_copy_out(unsigned *__restrict__ dst, const unsigned *__restrict__ src,
+                                              int n, int lane)
+{
+    if ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        const int n4 = n & ~3;
+        for (int o = lane * 4; o < n4; o += 4 * kWave)
+            st_out(reinterpret_cast<u32x4 *>(dst + o), *reinterpret_cast<const u32x4 *>(src + o));
+        if (lane < n - n4) st_out(dst + n4 + lane, src[n4 + lane]);
+    } else {
+        for (int o = lane; o < n; o += kWave) st_out(dst + o, src[o]);
+    }
+}
+
+// Workgroup geometries
+//   kPacked  : N <= 64.  256 threads = 4 independent waves; each wave holds floor(64/N) whole envs and
+//              touches only its own LDS, so all synchronisation is wave-local (no s_barrier).
+//   kSym64   : kPacked specialised for N == 64 without far agents: every unordered pair is evaluated
+//              ONCE (lane i tests partners i+1..i+32; the verdict reaches the partner as a rotated
+//              ballot), halving the far-filter arithmetic.
+//   kBlock256 / kBlock1024 : N > 64, one workgroup per env, thread = agent.
+enum Geo { kPacked = 0, kSym64 = 1, kBlock256 = 2, kBlock1024 = 3 };
+
+template <int GEO> struct GeoTraits {
+    static constexpr int kMaxThreads = GEO == kBlock1024 ? 1024 : 256;
+    static constexpr bool kWaveLocal = GEO == kPacked || GEO == kSym64;
+};
+
+template <bool WAVE_LOCAL>
+__device__ __forceinline__ void group_sync()
+{
+    if (WAVE_LOCAL) {          // a wave's own LDS traffic is ordered; only the compiler must not reorder
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int K, bool FAR, int MODE, int GEO>
+__global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(const KArgs a)
+{
+    constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
+    constexpr bool SYM = GEO == kSym64;
+    static_assert(!(SYM && FAR), "the symmetric filter assumes far agents never matter");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TRACE_MARK(0);
+    const int N = SYM ? 64 : a.N;
     const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = blockDim.x >> 6;
     int slot, agent;
     bool valid;
-    if (a.P > 0) {                                           // one wave per workgroup, P envs packed in it
-        const int sub = tid / N;
-        slot = sub;
-        agent = tid - sub * N;
+    if (WL) {                                                // lane -> (env slot inside the wave, agent)
+        const int sub = SYM ? 0 : lane / N;
+        slot = wave * a.P + sub;
+        agent = lane - sub * N;
         valid = sub < a.P;
     } else {
         slot = 0;
@@ -115,47 +180,81 @@ __global__ void __launch_bounds__(MAXT) drone_kernel(const KArgs a)
     }
     const int env = blockIdx.x * a.epb + slot;
     valid = valid && env < a.E;
-    if (MODE == kObserve && valid && a.mask != nullptr) valid = a.mask[env] != 0;
-
-    for (int s = tid; s < 2 * a.epb; s += blockDim.x) sred[s] = 0;
-    for (int s = tid; s < N; s += blockDim.x) sconst[s] = make_float2(a.delta[s], a.radius[s]);
-
-    // per-agent constants (shared by all envs; L2 resident)
-    float xFx = 0.f, xFy = 0.f, dhat = 1.f, delta_i = 0.f, li = 0.f;
-    if (valid) {
-        const float2 g = reinterpret_cast<const float2 *>(a.xF)[agent];
-        xFx = g.x; xFy = g.y;
-        dhat = a.d_hat[agent];
-        delta_i = a.delta[agent];
-        li = a.radius[agent];
-    }
-    const float reach = dhat + li + a.radius_max;
-    const float thr = reach * reach * 1.000001f;             // early-out radius^2 (conservative)
-    const float log2_dhat = __builtin_amdgcn_logf(dhat);     // v_log_f32 = log2
+    const bool masked = MODE == kObserve && a.mask != nullptr;
+    if (masked && valid) valid = a.mask[env] != 0;
     const size_t ga = (size_t)env * N + agent;               // global agent index
     const size_t step_agents = (size_t)a.E * N;              // rollout: per-step output stride
 
+    // ---- longest-latency loads first: this agent's state (HBM), then the shared constants (L2)
     float xi = 0.f, yi = 0.f, vxi = 0.f, vyi = 0.f;
+    float2 u0 = make_float2(0.f, 0.f);
     int tcur = 0;
+    float xFx = 0.f, xFy = 0.f, dhat = 1.f, delta_i = 0.f, li = 0.f;
     if (valid) {
         const float2 p = reinterpret_cast<const float2 *>(a.pos)[ga];
-        xi = p.x; yi = p.y;
         if (MODE == kObserve) {
             const float2 v = reinterpret_cast<const float2 *>(a.vel)[ga];
             vxi = v.x; vyi = v.y;
-        } else if (agent == 0) {
-            tcur = a.t[env];
+        } else {
+            u0 = reinterpret_cast<const float2 *>(a.act)[ga];
+            if (agent == 0) tcur = a.t[env];
         }
+        const float2 g = reinterpret_cast<const float2 *>(a.xF)[agent];
+        dhat = a.d_hat[agent];
+        delta_i = a.delta[agent];
+        li = a.radius[agent];
+        xi = p.x; yi = p.y;
+        xFx = g.x; xFy = g.y;
     }
+
+    // ---- LDS carve-up (all region sizes multiples of 16 bytes); wave-local geometries give every wave
+    //      its own copy of the (Delta_j, l_j) table so that no cross-wave barrier is ever needed
+    const int stride = 2 * N + kPad;                         // float2 per env slot
+    const int nconst = WL ? nwaves : 1;
+    float2 *spos = reinterpret_cast<float2 *>(smem);                                       // [epb][stride]
+    float2 *sconst_all = spos + (size_t)a.epb * stride;                                    // [nconst][N + (N&1)]
+    int *sred = reinterpret_cast<int *>(sconst_all + (size_t)nconst * (N + (N & 1)));      // [epb][2]
+    const int nred = 2 * a.epb + ((2 * a.epb) & 3 ? 4 - ((2 * a.epb) & 3) : 0);
+    unsigned *sstage = reinterpret_cast<unsigned *>(sred + nred);
+    constexpr int kZRow = 2 * (K + 1), kNRow = K + 1;        // words per agent in the c = 2 layout
+    unsigned *stage_z = sstage + (size_t)wave * kWave * (kZRow + kNRow);                   // [64][kZRow]
+    unsigned *stage_n = stage_z + kWave * kZRow;                                           // [64][kNRow]
+    float2 *sconst = sconst_all + (WL ? (size_t)wave * (N + (N & 1)) : 0);
+
+    if (WL) {
+        if (lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;
+        if (lane < N) sconst[lane] = make_float2(a.delta[lane], a.radius[lane]);
+    } else {
+        if (tid < 2) sred[tid] = 0;
+        for (int s = tid; s < N; s += blockDim.x) sconst[s] = make_float2(a.delta[s], a.radius[s]);
+    }
+
+    const float reach = SYM ? a.reach_max : dhat + li + a.radius_max;
+    const float thr = reach * reach * 1.000001f;             // early-out radius^2 (conservative)
+    const float log2_dhat = __builtin_amdgcn_logf(dhat);     // v_log_f32 = log2
     float2 *spos_env = spos + (size_t)slot * stride;
     const int nsteps = (MODE == kRollout) ? a.T : 1;
+    const bool staged = a.c == 2 && !masked;                 // z / Ni leave through LDS as full lines
+
+    // contiguous range of global agents covered by this wave (for the staged copy-out)
+    size_t wave_ga0;
+    int nval;
+    if (WL) {
+        const int env0 = blockIdx.x * a.epb + wave * a.P;
+        wave_ga0 = (size_t)env0 * N;
+        nval = max(0, min(a.P, a.E - env0)) * N;
+    } else {
+        wave_ga0 = (size_t)env * N + (size_t)wave * kWave;
+        nval = max(0, min(kWave, N - wave * kWave));
+    }
 
     for (int step = 0; step < nsteps; ++step) {
         const size_t so = (MODE == kRollout) ? (size_t)step * step_agents : 0;   // output offset (agents)
         const float *velsrc = (MODE == kObserve) ? a.vel : a.act + 2 * so;       // v of other agents
         if (valid) {
             if (MODE != kObserve) {
-                const float2 u = reinterpret_cast<const float2 *>(a.act)[so + ga];
+                const float2 u = (MODE == kRollout && step > 0)
+                                     ? reinterpret_cast<const float2 *>(a.act)[so + ga] : u0;
                 xi = fmaf(a.dt, u.x, xi);                     // drone_env.py:235
                 yi = fmaf(a.dt, u.y, yi);
                 vxi = u.x; vyi = u.y;                         // drone_env.py:238
@@ -163,8 +262,12 @@ __global__ void __launch_bounds__(MAXT) drone_kernel(const KArgs a)
             spos_env[agent] = make_float2(xi, yi);
             spos_env[agent + N] = make_float2(xi, yi);
         }
-        __syncthreads();
+        TRACE_MARK(1);
+        group_sync<WL>();
+        TRACE_MARK(2);
 
+        float zrx[K + 1], zry[K + 1];
+        int nbv[K + 1];
         if (valid) {
             float s_all = 0.f, s_msk = 0.f;
             int ncoll = 0;
@@ -177,11 +280,38 @@ __global__ void __launch_bounds__(MAXT) drone_kernel(const KArgs a)
             int in_range = ((dii <= delta_i) ? 1 : 0) - 1;    // :346 (N_delta[i,i] uses Delta_i), minus itself
 
             for (int r0 = 1; r0 < N; r0 += 64) {
-                // ---- pass 1: far filter over up to 64 partners, 16 LDS reads in flight
+                // ---- pass 1: far filter, 16 LDS reads in flight.  Result: one bit per partner to revisit.
                 unsigned long long near = 0ull;
                 const int left = N - r0;
+#if defined(DRONESIM_ABLATE_PASS1)
+                if (true) { near = (xi == 123.456f) ? 1ull : 0ull; } else
+#endif
                 if (FAR) {
                     near = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+                } else if (SYM) {
+                    // bit u < 32: partner i+1+u ("forward");  bit 32+u: partner i-1-u ("backward", u < 31)
+                    unsigned mf = 0u, mb = 0u;
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) {
+                        const float2 *pp = spos_env + agent + 1 + c2 * kChunk;
+                        float2 pj[kChunk];
+#pragma unroll
+                        for (int u = 0; u < kChunk; ++u) pj[u] = pp[u];
+#pragma unroll
+                        for (int u = 0; u < kChunk; ++u) {
+                            const int r = 1 + c2 * kChunk + u;                // 1..32
+                            const float dx = xi - pj[u].x, dy = yi - pj[u].y;
+                            const float d2 = fmaf(dy, dy, dx * dx);
+                            const bool f = d2 < thr;
+                            mf |= (f ? 1u : 0u) << (r - 1);
+                            if (r < 32) {                                     // r = 32: both ends see it as forward
+                                const unsigned long long fm = __builtin_amdgcn_ballot_w64(f);
+                                const unsigned long long bm = (fm << r) | (fm >> (64 - r));   // lane i -> lane i+r
+                                mb |= (__builtin_amdgcn_inverse_ballot_w64(bm) ? 1u : 0u) << (r - 1);
+                            }
+                        }
+                    }
+                    near = (unsigned long long)mf | ((unsigned long long)mb << 32);
                 } else {
 #pragma unroll
                     for (int c4 = 0; c4 < 4; ++c4) {
@@ -204,10 +334,13 @@ __global__ void __launch_bounds__(MAXT) drone_kernel(const KArgs a)
                     }
                 }
                 // ---- pass 2: every lane walks its own surviving partners
+#if defined(DRONESIM_ABLATE_PASS2)
+                s_all += (float)__builtin_popcountll(near); near = 0ull;
+#endif
                 while (near) {
                     const int u = __builtin_ctzll(near);
                     near &= near - 1ull;
-                    int j = agent + r0 + u;
+                    int j = SYM ? (u < 32 ? agent + 1 + u : agent + 95 - u) : agent + r0 + u;
                     const float2 pj = spos_env[j];
                     j -= (j >= N) ? N : 0;
                     const float2 cj = sconst[j];                              // (Delta_j, l_j)
@@ -227,61 +360,79 @@ __global__ void __launch_bounds__(MAXT) drone_kernel(const KArgs a)
                 }
             }
 
+            TRACE_MARK(3);
             // rewards (:276, :287-288)
             const float gx = xFx - xi, gy = xFy - yi;
             const float err2 = fmaf(gy, gy, gx * gx);
             const float to_goal = a.q * err2;
-            if (a.reward) a.reward[so + ga] = -nan_to_num_f32(fmaf(a.b, s_msk, to_goal));
-            if (a.true_reward) a.true_reward[so + ga] = -nan_to_num_f32(fmaf(a.b, s_all, to_goal));
+            if (a.reward) st_out(a.reward + so + ga, -nan_to_num_f32(fmaf(a.b, s_msk, to_goal)));
+            if (a.true_reward) st_out(a.true_reward + so + ga, -nan_to_num_f32(fmaf(a.b, s_all, to_goal)));
 
             // localized state rows + neighbour list (:344-397)
-            const int c = a.c;
-            float *zr = a.z + (so + ga) * (size_t)((K + 1) * c);
-            int *nb = a.nbr_idx + (so + ga) * (size_t)(K + 1);
             const float zx = xi - xFx, zy = yi - xFy;                         // :357
             const float gsc = __builtin_amdgcn_rsqf(err2) * delta_i * a.ghost_factor;
             const float ghx = zx * gsc, ghy = zy * gsc;                       // :386 (NaN when on the goal)
-            if (c == 2) {
-                reinterpret_cast<float2 *>(zr)[0] = make_float2(zx, zy);
-            } else {
-                zr[0] = zx; zr[1] = zy; zr[2] = vxi; zr[3] = vyi; zr[4] = li;
-            }
-            nb[0] = agent;
+            zrx[0] = zx; zry[0] = zy; nbv[0] = agent;
+            bool have[K + 1];
+            have[0] = true;
 #pragma unroll
             for (int kth = 1; kth <= K; ++kth) {
                 const unsigned j = (unsigned)list[kth];
-                const bool have = j < (unsigned)N;
-                const bool real = kth <= in_range && have;                    // :362
+                have[kth] = j < (unsigned)N;
+                const bool real = kth <= in_range && have[kth];               // :362
                 float rx = ghx, ry = ghy;
                 if (real) {
                     const float2 pj = spos_env[j];
                     rx = pj.x - xi; ry = pj.y - yi;                           // :368
                 }
-                nb[kth] = real ? (int)j : -1;
-                if (c == 2) {
-                    reinterpret_cast<float2 *>(zr)[kth] = make_float2(rx, ry);
-                } else {
-                    float *row = zr + kth * 5;
-                    row[0] = rx; row[1] = ry;
-                    if (have) {                                               // :367 / :385
-                        const float2 vj = reinterpret_cast<const float2 *>(velsrc)[(size_t)env * N + j];
-                        row[2] = vj.x; row[3] = vj.y; row[4] = sconst[j].y;
-                    } else {
-                        row[2] = row[3] = row[4] = __builtin_nanf("");
+                zrx[kth] = rx; zry[kth] = ry;
+                nbv[kth] = real ? (int)j : -1;
+            }
+            if (!staged) {                                                    // c = 5 rows / masked observe
+                const int c = a.c;
+                float *zr = a.z + (so + ga) * (size_t)((K + 1) * c);
+                int *nb = a.nbr_idx + (so + ga) * (size_t)(K + 1);
+#pragma unroll
+                for (int kth = 0; kth <= K; ++kth) {
+                    nb[kth] = nbv[kth];
+                    float *row = zr + kth * c;
+                    row[0] = zrx[kth]; row[1] = zry[kth];
+                    if (c == 5) {
+                        if (kth == 0) {
+                            row[2] = vxi; row[3] = vyi; row[4] = li;          // :355
+                        } else if (have[kth]) {                               // :367 / :385
+                            const unsigned j = (unsigned)list[kth];
+                            const float2 vj = reinterpret_cast<const float2 *>(velsrc)[(size_t)env * N + j];
+                            row[2] = vj.x; row[3] = vj.y; row[4] = sconst[j].y;
+                        } else {
+                            row[2] = row[3] = row[4] = __builtin_nanf("");
+                        }
                     }
                 }
             }
 
             if (MODE != kObserve) {
                 if (MODE != kRollout || step == nsteps - 1) {                 // final state only
-                    reinterpret_cast<float2 *>(a.pos)[ga] = make_float2(xi, yi);
-                    reinterpret_cast<float2 *>(a.vel)[ga] = make_float2(vxi, vyi);
+                    st_out2(a.pos + 2 * ga, xi, yi);
+                    st_out2(a.vel + 2 * ga, vxi, vyi);
                 }
                 if (!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius)) atomicOr(&sred[2 * slot + 1], 1);   // :249-251
             }
             if (ncoll) atomicAdd(&sred[2 * slot], ncoll);
         }
-        __syncthreads();
+        if (staged && valid) {                                // this lane's rows -> the wave's staging area
+#pragma unroll
+            for (int kth = 0; kth <= K; ++kth) {
+                reinterpret_cast<float2 *>(stage_z)[lane * (K + 1) + kth] = make_float2(zrx[kth], zry[kth]);
+                stage_n[lane * kNRow + kth] = (unsigned)nbv[kth];
+            }
+        }
+        TRACE_MARK(4);
+        group_sync<WL>();
+        if (staged && nval > 0) {
+            wave_copy_out(reinterpret_cast<unsigned *>(a.z) + (so + wave_ga0) * kZRow, stage_z, nval * kZRow, lane);
+            wave_copy_out(reinterpret_cast<unsigned *>(a.nbr_idx) + (so + wave_ga0) * kNRow, stage_n, nval * kNRow, lane);
+        }
         if (valid && agent == 0) {
             const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
             if (a.n_coll) a.n_coll[eo] = sred[2 * slot];
@@ -292,8 +443,17 @@ __global__ void __launch_bounds__(MAXT) drone_kernel(const KArgs a)
             sred[2 * slot] = 0;
             sred[2 * slot + 1] = 0;
         }
+        if (MODE == kRollout) group_sync<WL>();               // staging / sred reuse by the next step
     }
     if (MODE != kObserve && valid && agent == 0) a.t[env] = tcur;
+    TRACE_MARK(5);
+#if defined(DRONESIM_TRACE)
+    __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): all stores acknowledged
+    TRACE_MARK(6);
+    if (a.trace && (threadIdx.x & 63) == 0)
+        a.trace[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + 7] =
+            (long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);   // HW_REG_XCC_ID[3:0]
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -333,10 +493,11 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
     const int tid = threadIdx.x;
     int slot, agent;
     bool valid;
-    if (a.P > 0) {
-        const int sub = tid / N;
-        slot = sub;
-        agent = tid - sub * N;
+    if (a.P > 0) {                                           // same lane -> (slot, agent) map as drone_kernel
+        const int lane = tid & (kWave - 1);
+        const int sub = lane / N;
+        slot = (tid >> 6) * a.P + sub;
+        agent = lane - sub * N;
         valid = sub < a.P;
     } else {
         slot = 0; agent = tid; valid = tid < N;
@@ -391,6 +552,9 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
 
 // ---------------------------------------------------------------------------------------
 thread_local char g_err[256] = "";
+#if defined(DRONESIM_TRACE)
+long long *g_trace = nullptr;
+#endif
 
 int fail(int code, const char *msg)
 {
@@ -399,25 +563,40 @@ int fail(int code, const char *msg)
 }
 
 struct Geometry {
-    int P, epb, threads, blocks;
+    int P, epb, threads, blocks, geo;
     size_t lds;
 };
 
 Geometry geometry(int N, int E)
 {
     Geometry g;
-    if (N <= kWave) {                  // one wave = one workgroup: barriers are free, waves run unlocked
+    if (N <= kWave) {                  // 4 independent waves per workgroup, floor(64/N) envs per wave
         g.P = kWave / N;
-        g.threads = kWave;
-        g.epb = g.P;
+        g.threads = 256;
+        g.epb = 4 * g.P;
+        g.geo = kPacked;
     } else {
         g.P = 0;
         g.threads = ((N + kWave - 1) / kWave) * kWave;
         g.epb = 1;
+        g.geo = g.threads <= 256 ? kBlock256 : kBlock1024;
     }
     g.blocks = (E + g.epb - 1) / g.epb;
-    g.lds = sizeof(float2) * ((size_t)g.epb * (2 * (size_t)N + kPad) + (size_t)N) + sizeof(int) * 2 * (size_t)g.epb;
+    g.lds = 0;
     return g;
+}
+
+// dynamic LDS of drone_kernel (must mirror the carve-up in the kernel)
+size_t drone_lds_bytes(const Geometry &g, int N, int k)
+{
+    const size_t nwaves = (size_t)g.threads / kWave;
+    const size_t nconst = g.P > 0 ? nwaves : 1;
+    size_t b = sizeof(float2) * ((size_t)g.epb * (2 * (size_t)N + kPad) + nconst * ((size_t)N + (N & 1)));
+    size_t red = 2 * (size_t)g.epb;
+    red += (red & 3) ? 4 - (red & 3) : 0;
+    b += sizeof(int) * red;
+    b += sizeof(unsigned) * nwaves * kWave * 3 * (size_t)(k + 1);   // z (2 words) + Ni (1 word) per lane
+    return b;
 }
 
 int check_params(const DroneParams *p, int E)
@@ -429,50 +608,62 @@ int check_params(const DroneParams *p, int E)
     if (p->k > DRONESIM_MAX_K) return fail(DRONESIM_EUNSUPPORTED, "k_closest > DRONESIM_MAX_K");
     if (p->c != 2 && p->c != 5) return fail(DRONESIM_EINVAL, "c must be 2 or 5");
     if (!p->xF || !p->d_hat || !p->delta || !p->radius) return fail(DRONESIM_EINVAL, "constant array is NULL");
-    if (!(p->d_hat_min > 0.0f)) return fail(DRONESIM_EINVAL, "d_hat_min must be > 0");
+    if (!(p->d_hat_min > 0.0f) || !(p->d_hat_max >= p->d_hat_min))
+        return fail(DRONESIM_EINVAL, "need 0 < d_hat_min <= d_hat_max");
     return DRONESIM_OK;
 }
 
-template <int K, bool FAR, int MAXT>
+template <int K, bool FAR, int GEO>
 void launch_mode(int mode, const KArgs &a, const Geometry &g, hipStream_t s)
 {
     const dim3 grid(g.blocks), block(g.threads);
     switch (mode) {
-    case kStep: hipLaunchKernelGGL((drone_kernel<K, FAR, kStep, MAXT>), grid, block, g.lds, s, a); break;
-    case kObserve: hipLaunchKernelGGL((drone_kernel<K, FAR, kObserve, MAXT>), grid, block, g.lds, s, a); break;
-    default: hipLaunchKernelGGL((drone_kernel<K, FAR, kRollout, MAXT>), grid, block, g.lds, s, a); break;
+    case kStep: hipLaunchKernelGGL((drone_kernel<K, FAR, kStep, GEO>), grid, block, g.lds, s, a); break;
+    case kObserve: hipLaunchKernelGGL((drone_kernel<K, FAR, kObserve, GEO>), grid, block, g.lds, s, a); break;
+    default: hipLaunchKernelGGL((drone_kernel<K, FAR, kRollout, GEO>), grid, block, g.lds, s, a); break;
     }
 }
 
 template <int K>
 void launch_k(int mode, bool far, const KArgs &a, const Geometry &g, hipStream_t s)
 {
-    // register budget follows the workgroup size: one wave for N <= 64, 256 threads for N <= 256
-    // (covers every BASELINE config), 1024 threads only for the largest envs
-    if (g.threads <= 64) {
-        if (far) launch_mode<K, true, 64>(mode, a, g, s);
-        else launch_mode<K, false, 64>(mode, a, g, s);
-    } else if (g.threads <= 256) {
-        if (far) launch_mode<K, true, 256>(mode, a, g, s);
-        else launch_mode<K, false, 256>(mode, a, g, s);
-    } else {
-        if (far) launch_mode<K, true, 1024>(mode, a, g, s);
-        else launch_mode<K, false, 1024>(mode, a, g, s);
+    switch (g.geo) {
+    case kSym64: launch_mode<K, false, kSym64>(mode, a, g, s); break;
+    case kPacked:
+        if (far) launch_mode<K, true, kPacked>(mode, a, g, s);
+        else launch_mode<K, false, kPacked>(mode, a, g, s);
+        break;
+    case kBlock256:
+        if (far) launch_mode<K, true, kBlock256>(mode, a, g, s);
+        else launch_mode<K, false, kBlock256>(mode, a, g, s);
+        break;
+    default:
+        if (far) launch_mode<K, true, kBlock1024>(mode, a, g, s);
+        else launch_mode<K, false, kBlock1024>(mode, a, g, s);
+        break;
     }
 }
 
 int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
 {
     if (E == 0) return DRONESIM_OK;
-    const Geometry g = geometry(p->N, E);
+    Geometry g = geometry(p->N, E);
+    g.lds = drone_lds_bytes(g, p->N, p->k);
     a.N = p->N; a.c = p->c; a.max_steps = p->max_steps; a.E = E;
     a.P = g.P; a.epb = g.epb;
+#if defined(DRONESIM_TRACE)
+    a.trace = (mode == kStep) ? g_trace : nullptr;
+#endif
     a.dt = p->dt; a.q = p->q; a.b = p->b; a.done_radius = p->done_radius;
     a.ghost_factor = p->ghost_factor; a.radius_max = p->radius_max;
+    a.reach_max = p->d_hat_max + 2.0f * p->radius_max;
     a.xF = p->xF; a.d_hat = p->d_hat; a.delta = p->delta; a.radius = p->radius;
     // far agents matter when a z row carries (v, l) of a tie-ordered agent (c = 5) or
     // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)
     const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
+#if !defined(DRONESIM_NO_SYM64)
+    if (p->N == 64 && !far && p->d_hat_max >= p->d_hat_min) g.geo = kSym64;
+#endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (p->k) {
     case 1: launch_k<1>(mode, far, a, g, s); break;
@@ -565,6 +756,10 @@ int dronesim_reset(const DroneParams *p, int div_x, int div_y, float pitch,
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
 }
+
+#if defined(DRONESIM_TRACE)
+void dronesim_debug_set_trace(long long *buf) { g_trace = buf; }
+#endif
 
 const char *dronesim_last_error(void) { return g_err; }
 

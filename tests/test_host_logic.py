@@ -74,7 +74,7 @@ def test_params_struct_layout_matches_header():
     body = header[header.index("typedef struct DroneParams {"):header.index("} DroneParams;")]
     names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|float)\s*\*?\s*(\w+);", body, re.M)
     assert names == [f[0] for f in _native.DroneParams._fields_]
-    assert C.sizeof(_native.DroneParams) == 4 * 4 + 8 * 4 + 4 * 8
+    assert C.sizeof(_native.DroneParams) == 4 * 4 + 9 * 4 + 4 + 4 * 8      # 4-byte pad before the pointers
 
 
 def test_argument_errors_are_reported_without_a_gpu():

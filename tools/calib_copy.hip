@@ -51,3 +51,36 @@ int calib_write(void *z, void *nbr, size_t n_agents, void *stream)
     return (int)hipGetLastError();
 }
 }
+
+// ---- launch-floor probes (developer): how long does a dependent launch of B workgroups x T threads take
+// when each wave only (a) writes one dword, (b) streams `rd` bytes in and `wr` bytes out per thread?
+__global__ void probe_empty(unsigned *out)
+{
+    if ((threadIdx.x & 63) == 0) out[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = 1u;
+}
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+template <bool NT>
+__global__ void probe_stream(const f32x2_t *__restrict__ a, const f32x2_t *__restrict__ b, f32x2_t *__restrict__ o, int nout)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const f32x2_t x = a[i], y = b[i];
+    const size_t n = (size_t)gridDim.x * blockDim.x;
+    for (int k = 0; k < nout; ++k) {
+        f32x2_t v = x + y * (float)k;
+        if (NT) __builtin_nontemporal_store(v, o + (size_t)k * n + i); else o[(size_t)k * n + i] = v;
+    }
+}
+extern "C" {
+int probe_launch_empty(void *out, int blocks, int threads, void *stream)
+{
+    hipLaunchKernelGGL(probe_empty, dim3(blocks), dim3(threads), 0, static_cast<hipStream_t>(stream), (unsigned *)out);
+    return (int)hipGetLastError();
+}
+int probe_launch_stream(const void *a, const void *b, void *o, int blocks, int threads, int nout, int nt, void *stream)
+{
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (nt) hipLaunchKernelGGL(probe_stream<true>, dim3(blocks), dim3(threads), 0, s, (const f32x2_t *)a, (const f32x2_t *)b, (f32x2_t *)o, nout);
+    else hipLaunchKernelGGL(probe_stream<false>, dim3(blocks), dim3(threads), 0, s, (const f32x2_t *)a, (const f32x2_t *)b, (f32x2_t *)o, nout);
+    return (int)hipGetLastError();
+}
+}
