@@ -43,7 +43,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kChunk = 16;         // partners whose LDS reads are in flight together (pass 1)
-constexpr int kPad = kChunk;       // LDS slack so the last chunk may over-read
+constexpr int kPad = kChunk + 4;   // LDS slack so the last chunk may over-read (+ the shifted copy's offset)
 constexpr float kLn2 = 0.693147180559945309f;
 
 enum Mode { kStep = 0, kObserve = 1, kRollout = 2 };
@@ -163,26 +163,40 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
     static_assert(!(SYM && FAR), "the symmetric filter assumes far agents never matter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TRACE_MARK(0);
+#if defined(DRONESIM_EXP_PRIO)
+    // stagger co-resident waves: different workgroups get different issue priority, so their
+    // load / pair / store phases stop running in lockstep
+    switch ((blockIdx.x >> DRONESIM_EXP_PRIO) & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
+    }
+#endif
     const int N = SYM ? 64 : a.N;
     const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1), wave = tid >> 6, nwaves = blockDim.x >> 6;
-    int slot, agent;
-    bool valid;
+    const unsigned lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+    // Every wave covers a CONTIGUOUS range of global agents [wga0, wga0 + nval): lane l <-> agent wga0 + l.
+    // wga0 / nval are wave-uniform (SGPRs), so every per-agent array is addressed as uniform base + lane.
+    int slot, agent, env0, nval;
     if (WL) {                                                // lane -> (env slot inside the wave, agent)
-        const int sub = SYM ? 0 : lane / N;
+        const int sub = SYM ? 0 : (int)lane / N;
         slot = wave * a.P + sub;
-        agent = lane - sub * N;
-        valid = sub < a.P;
+        agent = (int)lane - sub * N;
+        env0 = blockIdx.x * a.epb + wave * a.P;
+        nval = max(0, min(a.P, a.E - env0)) * N;
     } else {
         slot = 0;
         agent = tid;
-        valid = tid < N;
+        env0 = blockIdx.x;
+        nval = max(0, min(kWave, N - wave * kWave));
     }
-    const int env = blockIdx.x * a.epb + slot;
-    valid = valid && env < a.E;
+    const size_t wga0 = (size_t)env0 * N + (WL ? 0 : wave * kWave);
+    const int env = env0 + (WL ? slot - wave * a.P : 0);
+    bool valid = (int)lane < nval;
     const bool masked = MODE == kObserve && a.mask != nullptr;
     if (masked && valid) valid = a.mask[env] != 0;
-    const size_t ga = (size_t)env * N + agent;               // global agent index
     const size_t step_agents = (size_t)a.E * N;              // rollout: per-step output stride
 
     // ---- longest-latency loads first: this agent's state (HBM), then the shared constants (L2)
@@ -191,28 +205,30 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
     int tcur = 0;
     float xFx = 0.f, xFy = 0.f, dhat = 1.f, delta_i = 0.f, li = 0.f;
     if (valid) {
-        const float2 p = reinterpret_cast<const float2 *>(a.pos)[ga];
+        const float2 p = (reinterpret_cast<const float2 *>(a.pos) + wga0)[lane];
         if (MODE == kObserve) {
-            const float2 v = reinterpret_cast<const float2 *>(a.vel)[ga];
+            const float2 v = (reinterpret_cast<const float2 *>(a.vel) + wga0)[lane];
             vxi = v.x; vyi = v.y;
         } else {
-            u0 = reinterpret_cast<const float2 *>(a.act)[ga];
+            u0 = (reinterpret_cast<const float2 *>(a.act) + wga0)[lane];
             if (agent == 0) tcur = a.t[env];
         }
-        const float2 g = reinterpret_cast<const float2 *>(a.xF)[agent];
-        dhat = a.d_hat[agent];
-        delta_i = a.delta[agent];
-        li = a.radius[agent];
+        const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
+        dhat = a.d_hat[(unsigned)agent];
+        delta_i = a.delta[(unsigned)agent];
+        li = a.radius[(unsigned)agent];
         xi = p.x; yi = p.y;
         xFx = g.x; xFy = g.y;
     }
 
     // ---- LDS carve-up (all region sizes multiples of 16 bytes); wave-local geometries give every wave
     //      its own copy of the (Delta_j, l_j) table so that no cross-wave barrier is ever needed
-    const int stride = 2 * N + kPad;                         // float2 per env slot
+    // positions of one env slot: S0[m] = dup[m] and S1[m + 1] = dup[m], dup = x_0..x_{N-1}, x_0..x_{N-1}
+    // (two copies one element apart, so every lane has a copy in which its partner window is 16-byte aligned)
+    const int stride = 2 * N + kPad;                         // float2 per copy (even)
     const int nconst = WL ? nwaves : 1;
-    float2 *spos = reinterpret_cast<float2 *>(smem);                                       // [epb][stride]
-    float2 *sconst_all = spos + (size_t)a.epb * stride;                                    // [nconst][N + (N&1)]
+    float2 *spos = reinterpret_cast<float2 *>(smem);                                       // [epb][2][stride]
+    float2 *sconst_all = spos + (size_t)a.epb * 2 * stride;                                // [nconst][N + (N&1)]
     int *sred = reinterpret_cast<int *>(sconst_all + (size_t)nconst * (N + (N & 1)));      // [epb][2]
     const int nred = 2 * a.epb + ((2 * a.epb) & 3 ? 4 - ((2 * a.epb) & 3) : 0);
     unsigned *sstage = reinterpret_cast<unsigned *>(sred + nred);
@@ -222,8 +238,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
     float2 *sconst = sconst_all + (WL ? (size_t)wave * (N + (N & 1)) : 0);
 
     if (WL) {
-        if (lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;
-        if (lane < N) sconst[lane] = make_float2(a.delta[lane], a.radius[lane]);
+        if ((int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;
+        if ((int)lane < N) sconst[lane] = make_float2(a.delta[lane], a.radius[lane]);
     } else {
         if (tid < 2) sred[tid] = 0;
         for (int s = tid; s < N; s += blockDim.x) sconst[s] = make_float2(a.delta[s], a.radius[s]);
@@ -232,21 +248,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
     const float reach = SYM ? a.reach_max : dhat + li + a.radius_max;
     const float thr = reach * reach * 1.000001f;             // early-out radius^2 (conservative)
     const float log2_dhat = __builtin_amdgcn_logf(dhat);     // v_log_f32 = log2
-    float2 *spos_env = spos + (size_t)slot * stride;
+    float2 *spos_env = spos + (size_t)slot * 2 * stride;     // S0 of this lane's env
+    // pass-1 window of this lane starts at dup index agent + (odd r): pick the copy where that is even
+    const float2 *pwin = (agent & 1) ? spos_env + agent + 1 : spos_env + stride + agent + 2;
     const int nsteps = (MODE == kRollout) ? a.T : 1;
     const bool staged = a.c == 2 && !masked;                 // z / Ni leave through LDS as full lines
-
-    // contiguous range of global agents covered by this wave (for the staged copy-out)
-    size_t wave_ga0;
-    int nval;
-    if (WL) {
-        const int env0 = blockIdx.x * a.epb + wave * a.P;
-        wave_ga0 = (size_t)env0 * N;
-        nval = max(0, min(a.P, a.E - env0)) * N;
-    } else {
-        wave_ga0 = (size_t)env * N + (size_t)wave * kWave;
-        nval = max(0, min(kWave, N - wave * kWave));
-    }
 
     for (int step = 0; step < nsteps; ++step) {
         const size_t so = (MODE == kRollout) ? (size_t)step * step_agents : 0;   // output offset (agents)
@@ -254,13 +260,15 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
         if (valid) {
             if (MODE != kObserve) {
                 const float2 u = (MODE == kRollout && step > 0)
-                                     ? reinterpret_cast<const float2 *>(a.act)[so + ga] : u0;
+                                     ? (reinterpret_cast<const float2 *>(a.act) + so + wga0)[lane] : u0;
                 xi = fmaf(a.dt, u.x, xi);                     // drone_env.py:235
                 yi = fmaf(a.dt, u.y, yi);
                 vxi = u.x; vyi = u.y;                         // drone_env.py:238
             }
             spos_env[agent] = make_float2(xi, yi);
             spos_env[agent + N] = make_float2(xi, yi);
+            spos_env[stride + agent + 1] = make_float2(xi, yi);
+            spos_env[stride + agent + N + 1] = make_float2(xi, yi);
         }
         TRACE_MARK(1);
         group_sync<WL>();
@@ -293,21 +301,26 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
                     unsigned mf = 0u, mb = 0u;
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
-                        const float2 *pp = spos_env + agent + 1 + c2 * kChunk;
+                        const float4 *pp = reinterpret_cast<const float4 *>(pwin + c2 * kChunk);   // dup index agent+1+16*c2
                         float2 pj[kChunk];
 #pragma unroll
-                        for (int u = 0; u < kChunk; ++u) pj[u] = pp[u];
+                        for (int u = 0; u < kChunk / 2; ++u) {            // ds_read_b128: two partners per read
+                            const float4 v = pp[u];
+                            pj[2 * u] = make_float2(v.x, v.y); pj[2 * u + 1] = make_float2(v.z, v.w);
+                        }
 #pragma unroll
                         for (int u = 0; u < kChunk; ++u) {
                             const int r = 1 + c2 * kChunk + u;                // 1..32
                             const float dx = xi - pj[u].x, dy = yi - pj[u].y;
                             const float d2 = fmaf(dy, dy, dx * dx);
                             const bool f = d2 < thr;
-                            mf |= (f ? 1u : 0u) << (r - 1);
-                            if (r < 32) {                                     // r = 32: both ends see it as forward
-                                const unsigned long long fm = __builtin_amdgcn_ballot_w64(f);
-                                const unsigned long long bm = (fm << r) | (fm >> (64 - r));   // lane i -> lane i+r
-                                mb |= (__builtin_amdgcn_inverse_ballot_w64(bm) ? 1u : 0u) << (r - 1);
+                            const unsigned long long fm = __builtin_amdgcn_ballot_w64(f);
+                            if (fm) {                                         // wave-uniform: ~2/3 of the offsets have no hit
+                                mf |= (f ? 1u : 0u) << (r - 1);
+                                if (r < 32) {                                 // r = 32: both ends see it as forward
+                                    const unsigned long long bm = (fm << r) | (fm >> (64 - r));   // lane i -> lane i+r
+                                    mb |= (__builtin_amdgcn_inverse_ballot_w64(bm) ? 1u : 0u) << (r - 1);
+                                }
                             }
                         }
                     }
@@ -317,10 +330,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
                     for (int c4 = 0; c4 < 4; ++c4) {
                         const int cnt = left - c4 * kChunk;
                         if (cnt > 0) {
-                            const float2 *pp = spos_env + agent + r0 + c4 * kChunk;
+                            const float4 *pp = reinterpret_cast<const float4 *>(pwin + (r0 - 1) + c4 * kChunk);
                             float2 pj[kChunk];
 #pragma unroll
-                            for (int u = 0; u < kChunk; ++u) pj[u] = pp[u];
+                            for (int u = 0; u < kChunk / 2; ++u) {        // ds_read_b128: two partners per read
+                                const float4 v = pp[u];
+                                pj[2 * u] = make_float2(v.x, v.y); pj[2 * u + 1] = make_float2(v.z, v.w);
+                            }
                             unsigned m = 0u;
 #pragma unroll
                             for (int u = 0; u < kChunk; ++u) {
@@ -365,8 +381,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
             const float gx = xFx - xi, gy = xFy - yi;
             const float err2 = fmaf(gy, gy, gx * gx);
             const float to_goal = a.q * err2;
-            if (a.reward) st_out(a.reward + so + ga, -nan_to_num_f32(fmaf(a.b, s_msk, to_goal)));
-            if (a.true_reward) st_out(a.true_reward + so + ga, -nan_to_num_f32(fmaf(a.b, s_all, to_goal)));
+            if (a.reward) st_out(a.reward + so + wga0 + lane, -nan_to_num_f32(fmaf(a.b, s_msk, to_goal)));
+            if (a.true_reward) st_out(a.true_reward + so + wga0 + lane, -nan_to_num_f32(fmaf(a.b, s_all, to_goal)));
 
             // localized state rows + neighbour list (:344-397)
             const float zx = xi - xFx, zy = yi - xFy;                         // :357
@@ -390,8 +406,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
             }
             if (!staged) {                                                    // c = 5 rows / masked observe
                 const int c = a.c;
-                float *zr = a.z + (so + ga) * (size_t)((K + 1) * c);
-                int *nb = a.nbr_idx + (so + ga) * (size_t)(K + 1);
+                float *zr = a.z + (so + wga0 + lane) * (size_t)((K + 1) * c);
+                int *nb = a.nbr_idx + (so + wga0 + lane) * (size_t)(K + 1);
 #pragma unroll
                 for (int kth = 0; kth <= K; ++kth) {
                     nb[kth] = nbv[kth];
@@ -413,14 +429,26 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
 
             if (MODE != kObserve) {
                 if (MODE != kRollout || step == nsteps - 1) {                 // final state only
-                    st_out2(a.pos + 2 * ga, xi, yi);
-                    st_out2(a.vel + 2 * ga, vxi, vyi);
+#if defined(DRONESIM_EXP_POS_CACHED)
+                    (reinterpret_cast<float2 *>(a.pos) + wga0)[lane] = make_float2(xi, yi);
+#else
+                    st_out2(a.pos + 2 * wga0 + 2 * lane, xi, yi);
+#endif
+                    st_out2(a.vel + 2 * wga0 + 2 * lane, vxi, vyi);
                 }
                 if (!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius)) atomicOr(&sred[2 * slot + 1], 1);   // :249-251
             }
             if (ncoll) atomicAdd(&sred[2 * slot], ncoll);
         }
+#if defined(DRONESIM_ABLATE_ZOUT)
+        if (valid) { float acc = 0.f;
+#pragma unroll
+            for (int kth = 0; kth <= K; ++kth) acc += zrx[kth] + zry[kth] + (float)nbv[kth];
+            asm volatile("" :: "v"(acc)); }
+        if (false) {
+#else
         if (staged && valid) {                                // this lane's rows -> the wave's staging area
+#endif
 #pragma unroll
             for (int kth = 0; kth <= K; ++kth) {
                 reinterpret_cast<float2 *>(stage_z)[lane * (K + 1) + kth] = make_float2(zrx[kth], zry[kth]);
@@ -429,9 +457,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
         }
         TRACE_MARK(4);
         group_sync<WL>();
+#if defined(DRONESIM_ABLATE_ZOUT)
+        if (false) {
+#else
         if (staged && nval > 0) {
-            wave_copy_out(reinterpret_cast<unsigned *>(a.z) + (so + wave_ga0) * kZRow, stage_z, nval * kZRow, lane);
-            wave_copy_out(reinterpret_cast<unsigned *>(a.nbr_idx) + (so + wave_ga0) * kNRow, stage_n, nval * kNRow, lane);
+#endif
+            wave_copy_out(reinterpret_cast<unsigned *>(a.z) + (so + wga0) * kZRow, stage_z, nval * kZRow, lane);
+            wave_copy_out(reinterpret_cast<unsigned *>(a.nbr_idx) + (so + wga0) * kNRow, stage_n, nval * kNRow, lane);
         }
         if (valid && agent == 0) {
             const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
@@ -591,7 +623,7 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k)
 {
     const size_t nwaves = (size_t)g.threads / kWave;
     const size_t nconst = g.P > 0 ? nwaves : 1;
-    size_t b = sizeof(float2) * ((size_t)g.epb * (2 * (size_t)N + kPad) + nconst * ((size_t)N + (N & 1)));
+    size_t b = sizeof(float2) * ((size_t)g.epb * 2 * (2 * (size_t)N + kPad) + nconst * ((size_t)N + (N & 1)));
     size_t red = 2 * (size_t)g.epb;
     red += (red & 3) ? 4 - (red & 3) : 0;
     b += sizeof(int) * red;
