@@ -178,6 +178,22 @@ def main():
         samples.append(e0.elapsed_time(e1) / n_samp)
     kern_ms = float(np.median(samples))
 
+    # secondary figure: the same workload through dronesim_rollout (200 steps fused in ONE launch, actions
+    # known up front -- RandomAgent rollouts); every per-step output except the per-step state is written
+    ro_us = None
+    try:
+        env.reset(renew_obstacles=False)
+        out = env.rollout(pool); torch.cuda.synchronize(); del out
+        rs = []
+        for _ in range(3):
+            env.reset(renew_obstacles=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = env.rollout(pool); e1.record(); torch.cuda.synchronize(); del out
+            rs.append(e0.elapsed_time(e1) * 1e3 / T_ep)
+        ro_us = float(np.median(rs))
+    except RuntimeError:                               # e.g. not enough memory for the [T, ...] outputs
+        ro_us = None
+
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -205,6 +221,9 @@ def main():
                          "kernel": "drone_kernel<K=2,FAR=0,step>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
             "episode_end_stats": summary,
+            "fused_rollout": None if ro_us is None else {
+                "us_per_step_per_gpu": ro_us, "agent_steps_per_s_per_gpu": N * E / ro_us * 1e6,
+                "note": "dronesim_rollout: 200 steps per launch, 52 B/agent-step (no per-step state write-back)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, G, delta, args.cpu_budget)

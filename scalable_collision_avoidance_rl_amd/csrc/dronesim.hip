@@ -259,8 +259,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
         const float *velsrc = (MODE == kObserve) ? a.vel : a.act + 2 * so;       // v of other agents
         if (valid) {
             if (MODE != kObserve) {
-                const float2 u = (MODE == kRollout && step > 0)
-                                     ? (reinterpret_cast<const float2 *>(a.act) + so + wga0)[lane] : u0;
+                const float2 u = u0;
+                if (MODE == kRollout && step + 1 < nsteps)    // prefetch the next step's action under this step's work
+                    u0 = (reinterpret_cast<const float2 *>(a.act) + so + step_agents + wga0)[lane];
                 xi = fmaf(a.dt, u.x, xi);                     // drone_env.py:235
                 yi = fmaf(a.dt, u.y, yi);
                 vxi = u.x; vyi = u.y;                         // drone_env.py:238

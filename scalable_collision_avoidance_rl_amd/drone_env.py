@@ -198,7 +198,10 @@ class drones:
         self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
         self._act = torch.zeros(E, N, 2, **f32)
         self._params_cache = None
+        self._step_args = None
         self.state = DroneState(self.pos, self.vel, self._radius) if self.batched else None
+        # step() hands back the same live tensors every call
+        self._result = StepResult(self.state, self.z, self.reward, self.n_coll, self.done, self.true_reward)
 
     def _params(self):
         """DroneParams for this launch (collision_weight is live: train_problem.py:31)."""
@@ -281,7 +284,7 @@ class drones:
                     and act.is_contiguous()):
                 act = torch.as_tensor(np.asarray(act, np.float32) if not torch.is_tensor(act) else act,
                                       dtype=torch.float32, device=self.device).contiguous()
-            if tuple(act.shape) != (self.n_envs, self.n_agents, 2):
+            if act.shape != self._act.shape:
                 raise ValueError(f"actions must be [{self.n_envs},{self.n_agents},2], got {tuple(act.shape)}")
         else:
             self._push_host_state()
@@ -290,15 +293,26 @@ class drones:
             self._act.copy_(torch.from_numpy(a).view(1, self.n_agents, 2), non_blocking=False)
             act = self._act
         p = self._params()
-        with torch.cuda.device(self.device):
-            rc = self._lib.dronesim_step(C.byref(p), self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
-                                         act.data_ptr(), self.reward.data_ptr(), self.true_reward.data_ptr(),
-                                         self.z.data_ptr(), self.nbr_idx.data_ptr(), self.n_coll.data_ptr(),
-                                         self.done.data_ptr(), self.n_envs, self._stream())
-        self._native.check(rc, "dronesim_step")
+        # host fast path: the buffer addresses never change, so the argument list is built once;
+        # only the action pointer and the current stream vary per call
+        args = self._step_args
+        if args is None:
+            args = self._step_args = [C.byref(p)] + [C.c_void_p(t.data_ptr()) for t in (
+                self.pos, self.vel, self.t, self._act, self.reward, self.true_reward, self.z, self.nbr_idx,
+                self.n_coll, self.done)] + [self.n_envs, None]
+        args[0] = C.byref(p)
+        args[4] = C.c_void_p(act.data_ptr())
+        if torch.cuda.current_device() == self.device.index:
+            args[12] = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = self._lib.dronesim_step(*args)
+        else:
+            with torch.cuda.device(self.device):
+                args[12] = self._stream()
+                rc = self._lib.dronesim_step(*args)
+        if rc:
+            self._native.check(rc, "dronesim_step")
         if self.batched:
-            return StepResult(DroneState(self.pos, self.vel, self._radius), self.z, self.reward, self.n_coll,
-                              self.done, self.true_reward)
+            return self._result
         self._sync_host_views()
         r = self.reward[0].double().cpu().numpy()
         tr = self.true_reward[0].double().cpu().numpy()
