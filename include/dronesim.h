@@ -115,6 +115,17 @@ int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, c
                      float *reward, float *true_reward, float *z, int32_t *nbr_idx,
                      int32_t *n_coll, uint8_t *done, int E, int T, void *stream);
 
+/* Classical controllers, batched (deterministic action sources for rollouts and tests):
+ *   kind DRONESIM_CONTROL_PROPORTIONAL  proportional_control(state, env)      drone_env.py:652-679
+ *        u = k_gain (xF - x), norm capped at u_max (reference: k_gain = 1, u_max = 1)
+ *   kind DRONESIM_CONTROL_GRADIENT      gradient_control(state, env, u_max)   drone_env.py:609-650
+ *        u = clip(-(2 (x - xF) - 0.1 sum_{j != i, d_ij <= dhat_i} (x_i - x_j) / (d_ij |x_i - x_j|)), +-u_max)
+ * pos [E][N][2] in, act [E][N][2] out.                                             */
+#define DRONESIM_CONTROL_PROPORTIONAL 0
+#define DRONESIM_CONTROL_GRADIENT 1
+int dronesim_control(const DroneParams *p, int kind, const float *pos, float *act, float u_max,
+                     int E, void *stream);
+
 const char *dronesim_last_error(void);
 const char *dronesim_error_string(int code);
 int dronesim_version(void);

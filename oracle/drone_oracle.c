@@ -408,3 +408,50 @@ int oracle_reset(int N, int div_x, int div_y, double pitch, uint64_t seed,
     free(node); free(cand); free(win);
     return rc;
 }
+
+/* ---------------------------------------------------------------------- */
+/* Classical controllers     drone_env.py:609-679         */
+
+/* gradient_control(state, env, u_max): log-barrier gradient over the complete graph.
+ * act[E][N][2].  b = 0.1, q = 1 as in the reference (:623-624).           drone_env.py:609-650 */
+int oracle_gradient_control(const OracleParams *p, const double *pos, double u_max, double *act, int E)
+{
+    const int N = p->N;
+    const double b = 0.1, q = 1.0;
+    for (int e = 0; e < E; ++e) {
+        const double *ps = pos + (size_t)e * N * 2;
+        for (int i = 0; i < N; ++i) {
+            const double xi = ps[2 * i], yi = ps[2 * i + 1];
+            const double t1x = 2 * (xi - p->xF[2 * i]), t1y = 2 * (yi - p->xF[2 * i + 1]);   /* :633 */
+            double t2x = 0.0, t2y = 0.0;
+            for (int j = 0; j < N; ++j) {
+                if (j == i) continue;
+                const double dx = xi - ps[2 * j], dy = yi - ps[2 * j + 1];
+                const double nrm = sqrt(dx * dx + dy * dy);
+                const double dij = nrm - p->radius[i] - p->radius[j];                        /* :641 */
+                if (dij <= p->d_hat[i]) { t2x += dx / (dij * nrm); t2y += dy / (dij * nrm); } /* :643-644 */
+            }
+            const double gx = q * t1x - b * t2x, gy = q * t1y - b * t2y;                     /* :646 */
+            act[((size_t)e * N + i) * 2 + 0] = fmin(fmax(-gx, -u_max), u_max);               /* :647 */
+            act[((size_t)e * N + i) * 2 + 1] = fmin(fmax(-gy, -u_max), u_max);
+        }
+    }
+    return 0;
+}
+
+/* proportional_control(state, env): saturated P-controller, u_max = 1, k_gain = 1.   drone_env.py:652-679 */
+int oracle_proportional_control(const OracleParams *p, const double *pos, double *act, int E)
+{
+    const int N = p->N;
+    const double u_max = 1.0, k_gain = 1.0;
+    for (int e = 0; e < E; ++e)
+        for (int i = 0; i < N; ++i) {
+            const double *x = pos + ((size_t)e * N + i) * 2;
+            double ux = k_gain * (p->xF[2 * i] - x[0]), uy = k_gain * (p->xF[2 * i + 1] - x[1]);   /* :667-668 */
+            const double nrm = sqrt(ux * ux + uy * uy);
+            if (nrm > u_max) { ux = ux / nrm * u_max; uy = uy / nrm * u_max; }                     /* :670-673 */
+            act[((size_t)e * N + i) * 2 + 0] = ux;
+            act[((size_t)e * N + i) * 2 + 1] = uy;
+        }
+    return 0;
+}

@@ -4,8 +4,8 @@ Drop-in for `/root/reference/drone_env.py` class `drones`; see drone_env.py in t
 package, include/dronesim.h (C ABI) and csrc/dronesim.hip (gfx950 kernels).
 Importing the package needs neither a GPU nor the built library; constructing an
 environment needs both (no CPU fallback)."""
-from .drone_env import (DroneState, StepResult, clip_deltas, dim, drones, dt, formation_O,
-                        lattice_divisions, max_time_steps, shard_range)
+from .drone_env import (DroneState, StepResult, clip_deltas, dim, drones, dt, formation_O, gradient_control,
+                        lattice_divisions, max_time_steps, proportional_control, shard_range)
 
 __all__ = ["drones", "DroneState", "StepResult", "dim", "dt", "max_time_steps", "formation_O",
-           "clip_deltas", "lattice_divisions", "shard_range"]
+           "clip_deltas", "lattice_divisions", "shard_range", "gradient_control", "proportional_control"]

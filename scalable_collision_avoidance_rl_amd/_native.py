@@ -16,11 +16,12 @@ LIB_PATH = os.environ.get("DRONESIM_LIB") or os.path.join(_PKG, "libdronesim.so"
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dronesim.h")
 
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
+CONTROL_PROPORTIONAL, CONTROL_GRADIENT = 0, 1
 MAX_K = 8
 MAX_AGENTS = 1024
 
 # every symbol include/dronesim.h declares (tests check the .so exports all of them)
-SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout",
+SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -60,6 +61,8 @@ def lib():
     L.dronesim_step.argtypes = [P] + [vp] * 10 + [i32, vp]
     L.dronesim_observe.argtypes = [P] + [vp] * 8 + [i32, vp]
     L.dronesim_rollout.argtypes = [P] + [vp] * 10 + [i32, i32, vp]
+    L.dronesim_control.argtypes = [P, i32, vp, vp, f32, i32, vp]
+    L.dronesim_control.restype = C.c_int
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
     for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset",
                  "dronesim_version"):

@@ -584,6 +584,84 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
+// Classical controllers (drone_env.py:609-679), same lane <-> agent geometry as drone_kernel.
+struct CArgs {
+    int N, E, P, epb, kind;
+    float u_max;
+    const float *xF, *d_hat, *radius, *pos;
+    float *act;
+};
+
+template <bool WL>
+__global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N;
+    const int tid = threadIdx.x;
+    const unsigned lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+    int slot, agent, env0, nval;
+    if (WL) {
+        const int sub = (int)lane / N;
+        slot = wave * a.P + sub;
+        agent = (int)lane - sub * N;
+        env0 = blockIdx.x * a.epb + wave * a.P;
+        nval = max(0, min(a.P, a.E - env0)) * N;
+    } else {
+        slot = 0; agent = tid; env0 = blockIdx.x;
+        nval = max(0, min(kWave, N - wave * kWave));
+    }
+    const size_t wga0 = (size_t)env0 * N + (WL ? 0 : wave * kWave);
+    const bool valid = (int)lane < nval;
+    float2 *spos = reinterpret_cast<float2 *>(smem);                         // [epb][N]
+    float *srad = reinterpret_cast<float *>(spos + (size_t)a.epb * N);       // [WL ? nwaves : 1][N]
+    float *srad_w = srad + (WL ? (size_t)wave * N : 0);
+    float xi = 0.f, yi = 0.f, xFx = 0.f, xFy = 0.f, dhat = 1.f, ri = 0.f;
+    if (valid) {
+        const float2 p = (reinterpret_cast<const float2 *>(a.pos) + wga0)[lane];
+        const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
+        dhat = a.d_hat[(unsigned)agent];
+        ri = a.radius[(unsigned)agent];
+        xi = p.x; yi = p.y; xFx = g.x; xFy = g.y;
+        spos[(size_t)slot * N + agent] = p;
+    }
+    if (WL) { if ((int)lane < N) srad_w[lane] = a.radius[lane]; }
+    else for (int s = tid; s < N; s += blockDim.x) srad_w[s] = a.radius[s];
+    (void)nwaves;
+    group_sync<WL>();
+    if (!valid) return;
+    float ux, uy;
+    if (a.kind == DRONESIM_CONTROL_PROPORTIONAL) {
+        ux = xFx - xi; uy = xFy - yi;                                        // :667-668, k_gain = 1
+        const float nrm = sqrtf(fmaf(uy, uy, ux * ux));
+        if (nrm > a.u_max) { ux = ux / nrm * a.u_max; uy = uy / nrm * a.u_max; }   // :670-673
+    } else {
+        const float2 *pe = spos + (size_t)slot * N;
+        float t2x = 0.f, t2y = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float2 pj = pe[j];
+            const float rj = srad_w[j];
+            const float dx = xi - pj.x, dy = yi - pj.y;
+            const float d2 = fmaf(dy, dy, dx * dx);
+            const float reach = dhat + ri + rj;
+            const bool cand = j != agent && d2 <= reach * reach * 1.000001f;
+            if (__builtin_amdgcn_ballot_w64(cand)) {                         // wave-uniform skip of the far majority
+                const float nrm = sqrtf(d2);
+                const float dij = nrm - ri - rj;                             // :641
+                if (cand && dij <= dhat) {                                   // :643
+                    const float w = 1.0f / (dij * nrm);
+                    t2x = fmaf(dx, w, t2x); t2y = fmaf(dy, w, t2y);          // :644
+                }
+            }
+        }
+        const float gx = 2.0f * (xi - xFx) - 0.1f * t2x, gy = 2.0f * (yi - xFy) - 0.1f * t2y;   // :633, :646
+        ux = fminf(fmaxf(-gx, -a.u_max), a.u_max);                           // :647
+        uy = fminf(fmaxf(-gy, -a.u_max), a.u_max);
+    }
+    (reinterpret_cast<float2 *>(a.act) + wga0)[lane] = make_float2(ux, uy);
+}
+
+// ---------------------------------------------------------------------------------------
 thread_local char g_err[256] = "";
 #if defined(DRONESIM_TRACE)
 long long *g_trace = nullptr;
@@ -785,6 +863,30 @@ int dronesim_reset(const DroneParams *p, int div_x, int div_y, float pitch,
     a.pos = pos; a.vel = vel; a.t = t; a.episode = episode; a.node_out = node_out;
     const size_t lds = sizeof(int) * 2 * (size_t)g.epb * p->N;
     hipLaunchKernelGGL(reset_kernel, dim3(g.blocks), dim3(g.threads), lds, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
+}
+
+int dronesim_control(const DroneParams *p, int kind, const float *pos, float *act, float u_max,
+                     int E, void *stream)
+{
+    if (!p) return fail(DRONESIM_EINVAL, "params is NULL");
+    if (p->N < 1 || p->N > DRONESIM_MAX_AGENTS) return fail(DRONESIM_EUNSUPPORTED, "N must be in 1..1024");
+    if (kind != DRONESIM_CONTROL_PROPORTIONAL && kind != DRONESIM_CONTROL_GRADIENT)
+        return fail(DRONESIM_EINVAL, "unknown controller kind");
+    if (E < 0 || !pos || !act || !p->xF || !p->d_hat || !p->radius)
+        return fail(DRONESIM_EINVAL, "dronesim_control: bad E or NULL buffer");
+    if (E == 0) return DRONESIM_OK;
+    const Geometry g = geometry(p->N, E);
+    CArgs a{};
+    a.N = p->N; a.E = E; a.P = g.P; a.epb = g.epb; a.kind = kind; a.u_max = u_max;
+    a.xF = p->xF; a.d_hat = p->d_hat; a.radius = p->radius; a.pos = pos; a.act = act;
+    const size_t nw = (size_t)g.threads / kWave;
+    const size_t lds = sizeof(float2) * (size_t)g.epb * p->N + sizeof(float) * (g.P > 0 ? nw : 1) * p->N;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (g.P > 0) hipLaunchKernelGGL(control_kernel<true>, dim3(g.blocks), dim3(g.threads), lds, s, a);
+    else hipLaunchKernelGGL(control_kernel<false>, dim3(g.blocks), dim3(g.threads), lds, s, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

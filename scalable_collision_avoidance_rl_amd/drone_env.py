@@ -355,6 +355,25 @@ class drones:
             self._sync_host_views()
         return out
 
+    def control(self, kind: str, u_max: float = 1.0):
+        """Batched classical controllers evaluated on the CURRENT state (drone_env.py:609-679):
+        ``kind`` = "proportional" or "gradient".  Returns actions ``[E,N,2]`` (device tensor) in batched
+        mode, a list of N float64 row vectors in compat mode -- directly usable as ``step()`` input."""
+        torch = self._torch
+        code = {"proportional": self._native.CONTROL_PROPORTIONAL, "gradient": self._native.CONTROL_GRADIENT}[kind]
+        if not self.batched:
+            self._push_host_state()
+        act = torch.empty_like(self._act)
+        p = self._params()
+        with torch.cuda.device(self.device):
+            rc = self._lib.dronesim_control(C.byref(p), code, self.pos.data_ptr(), act.data_ptr(), float(u_max),
+                                            self.n_envs, self._stream())
+        self._native.check(rc, "dronesim_control")
+        if self.batched:
+            return act
+        a = act[0].double().cpu().numpy()
+        return [a[i] for i in range(self.n_agents)]
+
     def get_local_states(self):
         """Current localized observation.  Compat: ``(z_states, Ni)`` (the attributes
         train_problem.py:85-86 reads).  Batched: ``(z [E,N,(k+1)c], nbr_idx [E,N,k+1], nbr_cnt [E,N])``
@@ -432,3 +451,18 @@ class drones:
         print("Deltas disk radius for each agent: \n", self.deltas)
         print(f"Collision cost weight (per unit of time) = {self.collision_weight} ")
         return ""
+
+
+def gradient_control(state, env, u_max=1):
+    """Drop-in for the reference's module-level `gradient_control(state, env, u_max)` (drone_env.py:609-650).
+    `state` is accepted for signature compatibility; in compat mode a modified `state` is uploaded first."""
+    if not env.batched and state is not env.state:
+        env.state[:, :] = state
+    return env.control("gradient", u_max)
+
+
+def proportional_control(state, env):
+    """Drop-in for the reference's `proportional_control(state, env)` (drone_env.py:652-679)."""
+    if not env.batched and state is not env.state:
+        env.state[:, :] = state
+    return env.control("proportional", 1.0)

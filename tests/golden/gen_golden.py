@@ -213,7 +213,37 @@ def gen_episode():
           f"min margin {np.min(rec['margin']):.2e}")
 
 
+def gen_controllers():
+    """gradient_control / proportional_control outputs on random states   drone_env.py:609-679"""
+    rng = np.random.default_rng(77)
+    data = {}
+    for (N, G, box) in [(4, 5, 2.5), (5, 5, 3.0), (64, 28, 9.0), (70, 32, 14.0)]:
+        env = quiet_env(N, 0, [G, G], "O", k_closest=1, deltas=np.ones(N), simplify_zstate=True)
+        pos, grad, prop, marg = [], [], [], []
+        while len(pos) < 8:
+            x = f32_exact(G / 2 + (rng.random((N, 2)) - 0.5) * box)
+            if len(pos) == 0:
+                x = f32_exact(env.end_points.reshape(N, 2) * 0.3 + G * 0.35)      # far from goals -> saturated
+            state = np.zeros((N, 5)); state[:, :2] = x; state[:, 4] = 0.1
+            # decisions: gap vs d_hat (d_ij <= d_hat_i) and vs 0 (sign flip of the barrier term)
+            d = np.linalg.norm(x[:, None] - x[None], axis=-1) - 0.2
+            np.fill_diagonal(d, 1e9)
+            m = min(np.abs(d - env.d_safety[:, None]).min(), np.abs(d).min())
+            if m < 1e-3:
+                continue
+            pos.append(x); marg.append(m)
+            grad.append(np.stack(drone_env.gradient_control(state, env)))
+            prop.append(np.stack(drone_env.proportional_control(state, env)))
+        data[f"pos_{N}_{G}"] = np.stack(pos); data[f"grad_{N}_{G}"] = np.stack(grad)
+        data[f"prop_{N}_{G}"] = np.stack(prop); data[f"margin_{N}_{G}"] = np.array(marg)
+    np.savez_compressed(os.path.join(OUT, "controllers.npz"), **data, **{f"meta_{a}": b for a, b in META.items()})
+    print("controllers:", len(data) // 4, "geometries x 8 states")
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "controllers":
+        gen_controllers()
+        return
     rng = np.random.default_rng(20240929)
     gen_formation()
     gen_init_states()
@@ -243,6 +273,7 @@ def main():
     gen_single_step("n70_c2", 70, 32, 2, True, np.ones(70), 6, 14.0, rng)
     gen_single_step("n256_c2", 256, 256, 2, True, np.ones(256) * 2.5, 3, 60.0, rng)
     gen_episode()
+    gen_controllers()
 
 
 if __name__ == "__main__":

@@ -122,3 +122,16 @@ def test_oracle_batching_and_threads_are_consistent():
         np.testing.assert_array_equal(a[k], b[k])
     one = o1.observe(fx["pos1"][3:4], fx["vel1"][3:4])
     np.testing.assert_array_equal(one["reward"][0], a["reward"][3])
+
+
+def test_controllers_match_reference():
+    """gradient_control / proportional_control (drone_env.py:609-679) on the reference's own outputs."""
+    fx = H.load("controllers.npz")
+    tags = [k[4:] for k in fx.files if k.startswith("pos_")]
+    assert len(tags) == 4
+    for tag in tags:
+        n, g = tag.split("_")
+        o = Oracle(int(n), [float(g), float(g)], 1, np.ones(int(n)), True)
+        H.assert_close(o.gradient_control(fx[f"pos_{tag}"]), fx[f"grad_{tag}"], f"grad {tag}", rtol=1e-10, atol=1e-10)
+        H.assert_close(o.proportional_control(fx[f"pos_{tag}"]), fx[f"prop_{tag}"], f"prop {tag}", **F64)
+        assert np.abs(fx[f"grad_{tag}"]).max() <= 1.0 and (np.abs(fx[f"grad_{tag}"]) == 1.0).any()   # clipped at u_max
