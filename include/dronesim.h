@@ -126,6 +126,20 @@ int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, c
 int dronesim_control(const DroneParams *p, int kind, const float *pos, float *act, float u_max,
                      int E, void *stream);
 
+/* Learner-side reductions over a stored rollout, buffers laid out [T][E][N] like the
+ * outputs of dronesim_rollout / T calls of dronesim_step:
+ *   dronesim_returns    Monte-Carlo return  G[t] = r[t] + gamma G[t+1],  G[T-1] = r[T-1]
+ *                       (SAC_agents.py:304-307); `done` ([T][E] uint8, may be NULL) restarts the scan:
+ *                       G[t] = r[t] where done[t] != 0.
+ *   dronesim_advantage  weight of the actor loss  w[t,i] = gamma^t / N * sum_{j in Ni[t]} (G[t,j] - V[t,i])
+ *                       (SAC_agents.py:333-351); nbr_idx [T][E][N][K1] is the neighbour list the action was
+ *                       based on (slot 0 = i, -1 = empty); with `done` the exponent restarts after every
+ *                       episode end.                                                            */
+int dronesim_returns(const float *reward, const uint8_t *done, float gamma, float *G,
+                     int T, int E, int N, void *stream);
+int dronesim_advantage(const float *G, const float *V, const int32_t *nbr_idx, const uint8_t *done,
+                       float gamma, float *w, int T, int E, int N, int K1, void *stream);
+
 const char *dronesim_last_error(void);
 const char *dronesim_error_string(int code);
 int dronesim_version(void);

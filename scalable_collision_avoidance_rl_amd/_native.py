@@ -21,7 +21,7 @@ MAX_K = 8
 MAX_AGENTS = 1024
 
 # every symbol include/dronesim.h declares (tests check the .so exports all of them)
-SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control",
+SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -63,6 +63,9 @@ def lib():
     L.dronesim_rollout.argtypes = [P] + [vp] * 10 + [i32, i32, vp]
     L.dronesim_control.argtypes = [P, i32, vp, vp, f32, i32, vp]
     L.dronesim_control.restype = C.c_int
+    L.dronesim_returns.argtypes = [vp, vp, f32, vp, i32, i32, i32, vp]
+    L.dronesim_advantage.argtypes = [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, vp]
+    L.dronesim_returns.restype = L.dronesim_advantage.restype = C.c_int
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
     for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset",
                  "dronesim_version"):

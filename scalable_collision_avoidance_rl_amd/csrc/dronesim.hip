@@ -662,6 +662,50 @@ __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
 }
 
 // ---------------------------------------------------------------------------------------
+// Learner-side scans over a stored rollout [T][E][N] (SAC_agents.py:304-307, 333-351).  One thread per
+// (env, agent) column; consecutive threads touch consecutive addresses at every t (coalesced streams).
+__global__ void __launch_bounds__(256) returns_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done,
+                                                      float gamma, float *__restrict__ G, int T, int E, int N)
+{
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t EN = (size_t)E * N;
+    if (col >= EN) return;
+    const size_t e = col / N;
+    float g = 0.0f;
+    for (int t = T - 1; t >= 0; --t) {
+        const float r = reward[(size_t)t * EN + col];
+        const bool last = t == T - 1 || (done != nullptr && done[(size_t)t * E + e] != 0);
+        g = last ? r : fmaf(g, gamma, r);                     // :306  Gt[t] = Gt[t+1]*discount + r[t]
+        G[(size_t)t * EN + col] = g;
+    }
+}
+
+__global__ void __launch_bounds__(256) advantage_kernel(const float *__restrict__ G, const float *__restrict__ V,
+                                                        const int *__restrict__ nbr, const uint8_t *__restrict__ done,
+                                                        float gamma, float *__restrict__ w, int T, int E, int N, int K1)
+{
+    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t EN = (size_t)E * N;
+    if (col >= EN) return;
+    const size_t e = col / N;
+    double disc = 1.0;                                         // gamma^t kept in double: 200 products stay exact to f32
+    const float inv_n = 1.0f / (float)N;
+    for (int t = 0; t < T; ++t) {
+        const size_t o = (size_t)t * EN + col;
+        const float v = V[o];
+        const int *nb = nbr + o * K1;
+        const float *Grow = G + (size_t)t * EN + e * N;
+        float adv = 0.0f;
+        for (int s = 0; s < K1; ++s) {
+            const int j = nb[s];
+            if (j >= 0) adv += Grow[j] - v;                   // :345-346  (i itself is slot 0)
+        }
+        w[o] = inv_n * (float)disc * adv;                      // :351
+        disc = (done != nullptr && done[(size_t)t * E + e] != 0) ? 1.0 : disc * (double)gamma;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 thread_local char g_err[256] = "";
 #if defined(DRONESIM_TRACE)
 long long *g_trace = nullptr;
@@ -887,6 +931,33 @@ int dronesim_control(const DroneParams *p, int kind, const float *pos, float *ac
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (g.P > 0) hipLaunchKernelGGL(control_kernel<true>, dim3(g.blocks), dim3(g.threads), lds, s, a);
     else hipLaunchKernelGGL(control_kernel<false>, dim3(g.blocks), dim3(g.threads), lds, s, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
+}
+
+int dronesim_returns(const float *reward, const uint8_t *done, float gamma, float *G,
+                     int T, int E, int N, void *stream)
+{
+    if (!reward || !G || T < 0 || E < 0 || N < 1) return fail(DRONESIM_EINVAL, "dronesim_returns: bad argument");
+    if (T == 0 || E == 0) return DRONESIM_OK;
+    const size_t cols = (size_t)E * N;
+    hipLaunchKernelGGL(returns_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reward, done, gamma, G, T, E, N);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
+}
+
+int dronesim_advantage(const float *G, const float *V, const int32_t *nbr_idx, const uint8_t *done,
+                       float gamma, float *w, int T, int E, int N, int K1, void *stream)
+{
+    if (!G || !V || !nbr_idx || !w || T < 0 || E < 0 || N < 1 || K1 < 1)
+        return fail(DRONESIM_EINVAL, "dronesim_advantage: bad argument");
+    if (T == 0 || E == 0) return DRONESIM_OK;
+    const size_t cols = (size_t)E * N;
+    hipLaunchKernelGGL(advantage_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       G, V, nbr_idx, done, gamma, w, T, E, N, K1);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

@@ -321,10 +321,12 @@ class drones:
         self.internal_t += 1
         return self.state, self.z_states, r, n_coll, finished, tr
 
-    def rollout(self, actions):
+    def rollout(self, actions, with_pre=False):
         """T fused steps in one launch with the actions known up front (RandomAgent-style rollouts,
         SAC_agents.py:9-22 + train_problem.py:82-107).  ``actions``: ``[T,E,N,2]`` float32 device tensor.
-        Returns a dict of ``[T, ...]`` tensors with every per-step output of step()."""
+        Returns a dict of ``[T, ...]`` tensors with every per-step output of step(); ``with_pre=True`` adds
+        ``z_pre`` / ``nbr_idx_pre``, the observation each action was based on (what the reference stores as
+        ``z_state`` / ``Ni`` in its experience tuples, utils.py:236-249)."""
         torch = self._torch
         E, N, K1, c = self.n_envs, self.n_agents, self.k_closest + 1, self.c
         act = actions.to(device=self.device, dtype=torch.float32).contiguous()
@@ -346,6 +348,9 @@ class drones:
                                             out["z"].data_ptr(), out["nbr_idx"].data_ptr(), out["n_coll"].data_ptr(),
                                             out["done"].data_ptr(), E, T, self._stream())
         self._native.check(rc, "dronesim_rollout")
+        if with_pre and T > 0:
+            out["z_pre"] = torch.cat([self.z.unsqueeze(0), out["z"][:-1]], dim=0)
+            out["nbr_idx_pre"] = torch.cat([self.nbr_idx.unsqueeze(0), out["nbr_idx"][:-1]], dim=0)
         if T > 0:
             self.z.copy_(out["z"][-1]); self.nbr_idx.copy_(out["nbr_idx"][-1])
             self.reward.copy_(out["reward"][-1]); self.true_reward.copy_(out["true_reward"][-1])

@@ -192,19 +192,41 @@ def gen_episode():
     env.collision_weight = 0.2
     agents = SA2CAgents(n_agents=N, dim_local_state=env.local_state_space,
                         dim_local_action=env.local_action_space, discount=0.99, epochs=10)
-    rec = {kk: [] for kk in ("act", "pos", "vel", "reward", "true_reward", "n_coll", "done", "z", "nbr_idx", "margin")}
+    from utils import ExperienceBuffers
+    rec = {kk: [] for kk in ("act", "pos", "vel", "reward", "true_reward", "n_coll", "done", "z", "nbr_idx", "margin",
+                             "nbr_idx_pre")}
     state0 = env.state.copy()
     z0 = np.stack(env.z_states); nbr0 = pack_ni(env.Ni, 3)
+    buffers = ExperienceBuffers(N)
     finished = False
     while not finished:
-        actions = agents.forward(env.z_states, env.Ni)            # deque of N arrays [2]
+        z_states, Ni = env.z_states, env.Ni
+        rec["nbr_idx_pre"].append(pack_ni(Ni, 3))
+        actions = agents.forward(z_states, Ni)                    # deque of N arrays [2]
         new_state, new_z, r, ncoll, finished, tr = env.step(actions)
+        buffers.append(z_states, actions, r, new_z, Ni, finished)  # train_problem.py:96
         m, _, _ = analyse(env, new_state)
         rec["act"].append(np.stack(list(actions))); rec["pos"].append(new_state[:, 0:2].copy())
         rec["vel"].append(new_state[:, 2:4].copy()); rec["reward"].append(r); rec["true_reward"].append(tr)
         rec["n_coll"].append(ncoll); rec["done"].append(finished); rec["z"].append(np.stack(new_z))
         rec["nbr_idx"].append(pack_ni(env.Ni, 3)); rec["margin"].append(m)
     data = {kk: np.stack(v) for kk, v in rec.items()}
+    # learner-side quantities of the same episode: Monte-Carlo returns and critic baselines as
+    # the reference computes them (SAC_agents.py:359-397), and the neighbour-summed advantage weight of the
+    # actor loss, evaluated with the reference's own objects exactly as lines :333-351 do
+    Gts, V_approxs = agents.benchmark_cirtic(buffers, only_one_NN=False)
+    T = len(rec["act"])
+    G = np.stack(list(Gts), axis=1)                     # [T, N]
+    V = np.stack(list(V_approxs), axis=1)               # [T, N] float32 critic outputs
+    w = np.zeros((T, N))
+    for i in range(N):
+        for t in range(T):
+            Nit = buffers.buffers[i][t].Ni
+            adv = 0
+            for j in Nit:
+                adv += (Gts[j][t] - V[t, i])
+            w[t, i] = 1 / N * agents.discount ** t * adv
+    data.update(mc_return=G, critic_value=V.astype(np.float64), adv_weight=w, discount=agents.discount)
     data.update(state0=state0, z0=z0, nbr0=nbr0, N=N, G=5.0, k=2, c=2, deltas=env.deltas, d_hat=env.d_safety,
                 xF=env.end_points.reshape(N, 2), collision_weight=0.2,
                 local_state_space=env.local_state_space, local_action_space=env.local_action_space)

@@ -441,3 +441,38 @@ def test_closed_loop_proportional_control_reaches_the_goal(torch):
     assert isinstance(acts, list) and len(acts) == N and acts[0].shape == (2,) and acts[0].dtype == np.float64
     new_state, *_ = e1.step(acts)
     assert new_state.shape == (N, 5)
+
+
+# ------------------------------------------------------------------------------- rollout storage
+def test_returns_and_advantage(torch):
+    """dronesim_returns / dronesim_advantage vs the reference's own episode quantities and the oracle."""
+    from oracle.oracle import mc_returns as o_ret, neighbour_advantage as o_adv
+    from scalable_collision_avoidance_rl_amd.rollout_buffer import mc_returns, neighbour_advantage
+    fx = H.load("episode_n5.npz")
+    gamma = float(fx["discount"])
+    dev = "cuda:0"
+    r = torch.tensor(fx["reward"][:, None, :], dtype=torch.float32, device=dev)
+    G = mc_returns(r, gamma)
+    H.assert_close(host(G)[:, 0], fx["mc_return"], "G vs reference")           # SAC_agents.py:381-385
+    V = torch.tensor(fx["critic_value"][:, None, :], dtype=torch.float32, device=dev)
+    nbr = torch.tensor(fx["nbr_idx_pre"][:, None], dtype=torch.int32, device=dev)
+    w = neighbour_advantage(G, V, nbr, gamma)
+    H.assert_close(host(w)[:, 0], fx["adv_weight"], "adv weight vs reference")  # SAC_agents.py:333-351
+    # a rollout's own storage, with episode boundaries
+    N, E, T = 64, 6, 40
+    env = make_env(N, 28.0, 2, 2, np.ones(N), E, seed=3)
+    env.t.fill_(180)                                     # the 200-step limit fires inside the rollout
+    g = torch.Generator(device=dev).manual_seed(2)
+    out = env.rollout(torch.rand(T, E, N, 2, device=dev, generator=g) * 2 - 1, with_pre=True)
+    assert int(out["done"].sum()) == E * (T - 19)        # done from step index 19 on (t >= 199)
+    done = out["done"].clone(); done[20:] = 0            # one boundary per env
+    G = mc_returns(out["reward"], 0.97, done)
+    ref_G = o_ret(host(out["reward"]), 0.97, host(done))
+    H.assert_close(host(G), ref_G, "G vs oracle")
+    Vr = torch.randn(T, E, N, device=dev, generator=g) * 5
+    w = neighbour_advantage(G, Vr, out["nbr_idx_pre"], 0.97, done)
+    ref_w = o_adv(ref_G, host(Vr), host(out["nbr_idx_pre"]), 0.97, host(done))
+    H.assert_close(host(w), ref_w, "adv vs oracle")
+    assert torch.equal(out["nbr_idx_pre"][1:], out["nbr_idx"][:-1]) and torch.equal(out["z_pre"][1:], out["z"][:-1])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mc_returns(torch.zeros(2, 2, 2), 0.9)

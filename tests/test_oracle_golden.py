@@ -135,3 +135,18 @@ def test_controllers_match_reference():
         H.assert_close(o.gradient_control(fx[f"pos_{tag}"]), fx[f"grad_{tag}"], f"grad {tag}", rtol=1e-10, atol=1e-10)
         H.assert_close(o.proportional_control(fx[f"pos_{tag}"]), fx[f"prop_{tag}"], f"prop {tag}", **F64)
         assert np.abs(fx[f"grad_{tag}"]).max() <= 1.0 and (np.abs(fx[f"grad_{tag}"]) == 1.0).any()   # clipped at u_max
+
+
+def test_returns_and_advantage_match_reference_episode():
+    """MC returns as SA2CAgents.benchmark_cirtic returns them and the actor-loss weight of train_NN
+    (SAC_agents.py:304-307, 333-351) on the C1 episode."""
+    from oracle.oracle import mc_returns, neighbour_advantage
+    fx = H.load("episode_n5.npz")
+    gamma = float(fx["discount"])
+    G = mc_returns(fx["reward"][:, None, :], gamma)
+    H.assert_close(G[:, 0], fx["mc_return"], "G", rtol=1e-12, atol=1e-12)
+    w = neighbour_advantage(G, fx["critic_value"][:, None, :], fx["nbr_idx_pre"][:, None], gamma)
+    H.assert_close(w[:, 0], fx["adv_weight"], "adv", rtol=1e-10, atol=1e-10)
+    # hand-checkable: T=3, gamma=0.5, rewards 1,2,4 -> G = 1+0.5*(2+0.5*4), 2+0.5*4, 4
+    assert mc_returns(np.array([1., 2., 4.]).reshape(3, 1, 1), 0.5).ravel().tolist() == [3.0, 4.0, 4.0]
+    assert mc_returns(np.array([1., 2., 4.]).reshape(3, 1, 1), 0.5, done=np.array([[0], [1], [0]])).ravel().tolist() == [2.0, 2.0, 4.0]
