@@ -140,6 +140,28 @@ int dronesim_returns(const float *reward, const uint8_t *done, float gamma, floa
 int dronesim_advantage(const float *G, const float *V, const int32_t *nbr_idx, const uint8_t *done,
                        float gamma, float *w, int T, int E, int N, int K1, void *stream);
 
+/* Batched per-agent policy / critic forward: N independent 3-layer MLPs, one per agent,
+ * evaluated on x[E][N][d_in] in one launch on the matrix cores in exact float32.
+ *   DiscreteSoftmaxNN  utils.py:255-309   d_in -> 300 relu -> 300 relu -> n_actions softmax; sample_kind 1
+ *                      draws the action index and returns the unit vector at angle 2 pi a / n_actions
+ *   NormalActorNN      utils.py:55-117    d_in -> 400 relu -> (200 | 200) relu -> (tanh mu[2] | sigmoid var[2]):
+ *                      pass the two heads concatenated as one 400-wide second layer and a block-diagonal
+ *                      [400][4] output matrix; sample_kind 2 draws a ~ N(mu, sqrt(var))
+ *   CriticNN           utils.py:14-53     d_in -> 200 relu -> 200 relu -> 1, out_kind 0
+ * Weights are stacked per agent, "in x out" row-major: w1 [N][d_in][h1], b1 [N][h1], w2 [N][h1][h2],
+ * b2 [N][h2], w3 [N][h2][nout], b3 [N][nout] (torch Linear stores [out][in]: transpose when importing).
+ * out [E][N][nout] (post-activation, may be NULL), act [E][N][2] and act_idx [E][N] (may be NULL).
+ * Random stream: Philox4x32-10 keyed by (seed, counter, env_base + e, agent).                       */
+typedef struct DroneMlp {
+    int32_t N, d_in, h1, h2, nout;
+    int32_t out_kind;       /* 0 identity, 1 softmax, 2 tanh(first half) + sigmoid(second half) */
+    int32_t sample_kind;    /* 0 none, 1 categorical -> unit-circle action, 2 Gaussian          */
+    int32_t reserved;
+    const float *w1, *b1, *w2, *b2, *w3, *b3;
+} DroneMlp;
+int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,
+                         uint64_t seed, uint64_t counter, int64_t env_base, int E, void *stream);
+
 const char *dronesim_last_error(void);
 const char *dronesim_error_string(int code);
 int dronesim_version(void);

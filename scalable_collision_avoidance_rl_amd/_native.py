@@ -21,7 +21,7 @@ MAX_K = 8
 MAX_AGENTS = 1024
 
 # every symbol include/dronesim.h declares (tests check the .so exports all of them)
-SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage",
+SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_mlp_forward",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -33,6 +33,14 @@ class DroneParams(C.Structure):
                 ("d_hat_min", C.c_float), ("d_hat_max", C.c_float), ("delta_max", C.c_float), ("radius_max", C.c_float),
                 ("xF", C.c_void_p), ("d_hat", C.c_void_p), ("delta", C.c_void_p),
                 ("radius", C.c_void_p)]
+
+
+class DroneMlp(C.Structure):
+    """Mirror of `struct DroneMlp` (include/dronesim.h)."""
+    _fields_ = [("N", C.c_int32), ("d_in", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("nout", C.c_int32),
+                ("out_kind", C.c_int32), ("sample_kind", C.c_int32), ("reserved", C.c_int32),
+                ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
+                ("w3", C.c_void_p), ("b3", C.c_void_p)]
 
 
 class DroneSimError(RuntimeError):
@@ -66,6 +74,8 @@ def lib():
     L.dronesim_returns.argtypes = [vp, vp, f32, vp, i32, i32, i32, vp]
     L.dronesim_advantage.argtypes = [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, vp]
     L.dronesim_returns.restype = L.dronesim_advantage.restype = C.c_int
+    L.dronesim_mlp_forward.argtypes = [C.POINTER(DroneMlp), vp, vp, vp, vp, u64, u64, i64, i32, vp]
+    L.dronesim_mlp_forward.restype = C.c_int
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
     for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset",
                  "dronesim_version"):

@@ -716,6 +716,12 @@ int fail(int code, const char *msg)
     snprintf(g_err, sizeof(g_err), "%s", msg);
     return code;
 }
+}   // namespace
+
+// shared with the other translation units of the library (csrc/common.hpp); not part of the C ABI
+__attribute__((visibility("hidden"))) int dronesim_fail(int code, const char *msg) { return fail(code, msg); }
+
+namespace {
 
 struct Geometry {
     int P, epb, threads, blocks, geo;

@@ -1,0 +1,239 @@
+// policy.hip -- batched per-agent 3-layer MLP forward + action sampling on gfx950 matrix cores.
+//
+// The reference evaluates one small torch MLP per agent per step in a Python loop
+// (SAC_agents.py:170-180 -> utils.py:304-309 / 110-117 / 40-53): with the environment on the device this
+// is the whole rollout time.  Here ALL agents' networks run in one launch over the
+// batched observation z[E][N][d_in]:
+//     h1 = relu(x W1_i + b1_i)        utils.py:291-292 / 91-92 / 42-43
+//     h2 = relu(h1 W2_i + b2_i)       utils.py:295-296 / 95-99 / 46-47
+//     y  = h2 W3_i + b3_i             utils.py:299 / 102-106 / 50
+//     out = softmax(y) | (tanh, sigmoid) | y       utils.py:300 / 103,106 / --
+// plus the sampling of sample_action (categorical over unit-circle actions utils.py:262-269,304-309;
+// Gaussian utils.py:110-117) from a counter-based Philox stream.
+//
+// Arithmetic: exact float32 on the matrix cores -- v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain
+// (no reduced precision), so results match a float32 torch reference to round-off.
+// Decomposition: grid = (ceil(E/64), N): one workgroup = 64 env rows of ONE agent, 4 waves.
+//   wave w owns row half (w & 1) and every second 32-column chunk of the hidden layers.
+//   layer 1: A = x tile (LDS), B = W1 (global/L2)            -> h1 tile in LDS [64][h1+1]
+//   layer 2 chunk (32 columns): A = h1 (LDS), B = W2          -> relu -> per-wave LDS staging [32][33]
+//   layer 3 partial: A = staged chunk, B = W3 rows of the chunk -> accumulated in registers
+//   partials of the two chunk-parities are summed through LDS, then activation + sampling.
+// LDS row strides are odd (h1+1, 33) so the 32-row fragment reads are bank-conflict free.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.hpp"
+#include "dronesim.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kRows = 64;            // env rows per workgroup
+constexpr int kMaxOut = 32;
+
+struct MArgs {
+    int E, N, d_in, h1, h2, nout, out_kind, sample_kind;
+    const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
+    float *out, *act;
+    int *act_idx;
+    uint32_t key0, key1, ctr2, ctr3;
+    long long env_base;
+};
+
+// C/D layout of v_mfma_f32_32x32x2_f32: element reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31)
+__device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// acc += A[32 x K] * B[K x 32]:  A row-major in LDS (lda floats per row), B row-major in global (ldb floats
+// per row); B columns >= ncols_valid and k >= K read as zero.
+__device__ __forceinline__ f32x16 tile_gemm(f32x16 acc, const float *A, int lda, const float *__restrict__ B, int ldb,
+                                            int K, int ncols_valid, int lane)
+{
+    const int ar = lane & 31, kk = lane >> 5;
+    const bool colok = ar < ncols_valid;
+    int k0 = 0;
+    for (; k0 + 8 <= K; k0 += 8) {                         // 4 MFMAs per trip, their 4+4 operand loads in flight
+        float av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 2 * u + kk;
+            av[u] = A[ar * lda + k];
+            bv[u] = colok ? B[(size_t)k * ldb + ar] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 2) {
+        const int k = k0 + kk;
+        const float av = k < K ? A[ar * lda + k] : 0.0f;
+        const float bv = (colok && k < K) ? B[(size_t)k * ldb + ar] : 0.0f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int agent = blockIdx.y;
+    const int e0 = blockIdx.x * kRows;
+    const int ldx = a.d_in + 1, ld1 = a.h1 + 1;
+    float *sx = reinterpret_cast<float *>(smem);                 // [64][d_in+1]
+    float *sh1 = sx + kRows * ldx;                               // [64][h1+1]
+    float *sst = sh1 + kRows * ld1;                              // [4 waves][32][33] layer-2 chunk staging
+    float *spart = sst + 4 * 32 * 33;                            // [4 waves][32][33] layer-3 partials
+    const float *w1 = a.w1 + (size_t)agent * a.d_in * a.h1, *b1 = a.b1 + (size_t)agent * a.h1;
+    const float *w2 = a.w2 + (size_t)agent * a.h1 * a.h2, *b2 = a.b2 + (size_t)agent * a.h2;
+    const float *w3 = a.w3 + (size_t)agent * a.h2 * a.nout, *b3 = a.b3 + (size_t)agent * a.nout;
+
+    // ---- x tile -> LDS (rows beyond E are zero)
+    for (int idx = tid; idx < kRows * a.d_in; idx += 256) {
+        const int r = idx / a.d_in, c = idx - r * a.d_in;
+        const int e = e0 + r;
+        sx[r * ldx + c] = e < a.E ? a.x[((size_t)e * a.N + agent) * a.d_in + c] : 0.0f;
+    }
+    __syncthreads();
+
+    const int rh = wave & 1, cp = wave >> 1;                     // row half, chunk parity of this wave
+    const int col = lane & 31;
+    // ---- layer 1
+    for (int c0 = cp * 32; c0 < a.h1; c0 += 64) {
+        f32x16 acc = {0};
+        acc = tile_gemm(acc, sx + rh * 32 * ldx, ldx, w1 + c0, a.h1, a.d_in, a.h1 - c0, lane);
+        const bool ok = c0 + col < a.h1;
+        const float bias = ok ? b1[c0 + col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (ok) sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc[r] + bias, 0.0f);
+    }
+    __syncthreads();
+
+    // ---- layers 2 + 3 fused over this wave's column chunks
+    f32x16 acc3 = {0};
+    float *st = sst + wave * 32 * 33;
+    for (int c0 = cp * 32; c0 < a.h2; c0 += 64) {
+        f32x16 acc = {0};
+        acc = tile_gemm(acc, sh1 + rh * 32 * ld1, ld1, w2 + c0, a.h2, a.h1, a.h2 - c0, lane);
+        const bool ok = c0 + col < a.h2;
+        const float bias = ok ? b2[c0 + col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = ok ? fmaxf(acc[r] + bias, 0.0f) : 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int kc = min(32, a.h2 - c0);
+        acc3 = tile_gemm(acc3, st, 33, w3 + (size_t)c0 * a.nout, a.nout, kc, a.nout, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    float *part = spart + wave * 32 * 33;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[cd_row(r, lane) * 33 + col] = acc3[r];
+    __syncthreads();
+
+    // ---- output activation + sampling: one thread per env row
+    if (tid < kRows) {
+        const int e = e0 + tid;
+        if (e >= a.E) return;
+        const int rhh = tid >> 5, rr = tid & 31;
+        const float *p0 = spart + (rhh + 0) * 32 * 33 + rr * 33, *p1 = spart + (rhh + 2) * 32 * 33 + rr * 33;
+        float y[kMaxOut];
+        const int nout = a.nout;
+#pragma unroll
+        for (int j = 0; j < kMaxOut; ++j) y[j] = j < nout ? p0[j] + p1[j] + b3[j] : 0.0f;
+        if (a.out_kind == 1) {                                   // softmax (utils.py:286, dim = 0 of one sample)
+            float m = -__builtin_inff();
+#pragma unroll
+            for (int j = 0; j < kMaxOut; ++j) if (j < nout) m = fmaxf(m, y[j]);
+            float ssum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kMaxOut; ++j) { y[j] = j < nout ? expf(y[j] - m) : 0.0f; ssum += y[j]; }
+            const float inv = 1.0f / ssum;
+#pragma unroll
+            for (int j = 0; j < kMaxOut; ++j) y[j] *= inv;
+        } else if (a.out_kind == 2) {                            // tanh means, sigmoid variances (utils.py:74-77)
+            const int half = nout / 2;
+#pragma unroll
+            for (int j = 0; j < kMaxOut; ++j)
+                if (j < nout) y[j] = j < half ? tanhf(y[j]) : 1.0f / (1.0f + expf(-y[j]));
+        }
+        const size_t row = (size_t)e * a.N + agent;
+        if (a.out) {
+#pragma unroll
+            for (int j = 0; j < kMaxOut; ++j) if (j < nout) a.out[row * nout + j] = y[j];
+        }
+        if (a.sample_kind != 0) {
+            uint32_t rnd[4];
+            philox4x32_10((uint32_t)agent, (uint32_t)(a.env_base + e), a.ctr2, a.ctr3, a.key0, a.key1, rnd);
+            if (a.sample_kind == 1) {                            // categorical -> unit vector (utils.py:262-269, 304-309)
+                const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+                float cdf = 0.0f;
+                int pick = nout - 1;
+                bool found = false;
+#pragma unroll
+                for (int j = 0; j < kMaxOut; ++j) {
+                    if (j < nout) {
+                        cdf += y[j];
+                        if (!found && u < cdf) { pick = j; found = true; }
+                    }
+                }
+                if (a.act_idx) a.act_idx[row] = pick;
+                if (a.act) {
+                    const float ang = (float)pick / (float)nout * 6.283185307179586f;
+                    a.act[row * 2 + 0] = cosf(ang);
+                    a.act[row * 2 + 1] = sinf(ang);
+                }
+            } else {                                             // Gaussian, Box-Muller (utils.py:110-117)
+                const int half = nout / 2;
+                for (int d = 0; d < half && d < 2; ++d) {
+                    const float u1 = ((float)(rnd[2 * d] >> 8) + 1.0f) * (1.0f / 16777216.0f);    // (0, 1]
+                    const float u2 = (float)(rnd[2 * d + 1] >> 8) * (1.0f / 16777216.0f);
+                    const float n01 = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+                    if (a.act) a.act[row * half + d] = fmaf(sqrtf(y[half + d]), n01, y[d]);
+                }
+            }
+        }
+    }
+}
+
+}   // namespace
+
+extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,
+                                    uint64_t seed, uint64_t counter, int64_t env_base, int E, void *stream)
+{
+    if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL argument");
+    if (m->N < 1 || m->d_in < 1 || m->d_in > 64 || m->h1 < 1 || m->h1 > 512 || m->h2 < 1 || m->h2 > 512 ||
+        m->nout < 1 || m->nout > kMaxOut)
+        return dronesim_fail(DRONESIM_EUNSUPPORTED, "dronesim_mlp_forward: need d_in<=64, h1,h2<=512, nout<=32");
+    if (!m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3)
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
+    if (m->out_kind < 0 || m->out_kind > 2 || m->sample_kind < 0 || m->sample_kind > 2)
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: bad out_kind / sample_kind");
+    if (m->sample_kind == 2 && (m->out_kind != 2 || m->nout != 4))
+        return dronesim_fail(DRONESIM_EINVAL, "Gaussian sampling needs out_kind 2 with nout = 4 (mu_x, mu_y, var_x, var_y)");
+    if (E < 0) return dronesim_fail(DRONESIM_EINVAL, "E < 0");
+    if (E == 0) return DRONESIM_OK;
+    MArgs a{};
+    a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2; a.nout = m->nout;
+    a.out_kind = m->out_kind; a.sample_kind = m->sample_kind;
+    a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
+    a.out = out; a.act = act; a.act_idx = act_idx;
+    a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32);
+    a.ctr2 = (uint32_t)counter; a.ctr3 = (uint32_t)(counter >> 32);
+    a.env_base = env_base;
+    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + 2 * 4 * 32 * 33);
+    static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
+    if (!big_lds_enabled) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return dronesim_fail(DRONESIM_ELAUNCH, "cannot enable 160 KiB of dynamic LDS for mlp3_kernel");
+        big_lds_enabled = true;
+    }
+    if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
+    hipLaunchKernelGGL(mlp3_kernel, dim3((E + kRows - 1) / kRows, m->N), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
+}

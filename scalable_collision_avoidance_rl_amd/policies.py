@@ -1,0 +1,122 @@
+"""Batched per-agent policies and critics.
+
+The reference keeps one small torch module per agent and evaluates them one by one in Python every step
+(SAC_agents.py:170-180: ``actors[i].sample_action(z_states[i].flatten(), N[i])``).  `BatchedMLP` stacks the
+N networks' weights and evaluates all of them on the batched observation ``z [E,N,d_in]`` in ONE launch
+of the HIP kernel in csrc/policy.hip (exact float32 on the matrix cores), including the sampling of
+``sample_action``.  Architectures mirrored:
+
+  DiscreteSoftmaxNN  utils.py:255-309   BatchedMLP.from_discrete_softmax(modules)
+  NormalActorNN      utils.py:55-117    BatchedMLP.from_normal_actor(modules)
+  CriticNN           utils.py:14-53     BatchedMLP.from_critic(modules)
+
+`modules` are any objects exposing the reference's attribute names (`input_layer`, `hidden_layer1`, ...,
+each with `.weight [out,in]` and `.bias`), e.g. the reference's own classes or plain namespaces of tensors.
+No CPU fallback: the forward pass needs the built HIP library and a GPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+OUT_IDENTITY, OUT_SOFTMAX, OUT_TANH_SIGMOID = 0, 1, 2
+SAMPLE_NONE, SAMPLE_CATEGORICAL, SAMPLE_GAUSSIAN = 0, 1, 2
+
+
+def _wt(layer):
+    """torch Linear stores [out, in]; the kernel reads [in, out]."""
+    return layer.weight.detach().t().contiguous().float(), layer.bias.detach().contiguous().float()
+
+
+class BatchedMLP:
+    def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0):
+        """w1 [N,d_in,h1], b1 [N,h1], w2 [N,h1,h2], b2 [N,h2], w3 [N,h2,nout], b3 [N,nout] (float32)."""
+        import torch
+        from . import _native
+        self._torch, self._native = torch, _native
+        self._lib = _native.lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchedMLP needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        f = lambda t: torch.as_tensor(t, dtype=torch.float32).to(self.device).contiguous()
+        self.w1, self.b1, self.w2, self.b2, self.w3, self.b3 = (f(t) for t in (w1, b1, w2, b2, w3, b3))
+        self.n_agents, self.d_in, self.h1 = self.w1.shape
+        self.h2, self.nout = self.w3.shape[1], self.w3.shape[2]
+        assert self.w2.shape == (self.n_agents, self.h1, self.h2) and self.b3.shape == (self.n_agents, self.nout)
+        self.out_kind, self.sample_kind = int(out_kind), int(sample_kind)
+        self.seed, self.counter = int(seed), 0
+        m = _native.DroneMlp()
+        m.N, m.d_in, m.h1, m.h2, m.nout = self.n_agents, self.d_in, self.h1, self.h2, self.nout
+        m.out_kind, m.sample_kind = self.out_kind, self.sample_kind
+        m.w1, m.b1, m.w2 = self.w1.data_ptr(), self.b1.data_ptr(), self.w2.data_ptr()
+        m.b2, m.w3, m.b3 = self.b2.data_ptr(), self.w3.data_ptr(), self.b3.data_ptr()
+        self._m = m
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_discrete_softmax(cls, modules, **kw):
+        """N x DiscreteSoftmaxNN: input_layer -> hidden_layer1 -> out_1, softmax (utils.py:271-302)."""
+        import torch
+        parts = [(_wt(m.input_layer), _wt(m.hidden_layer1), _wt(m.out_1)) for m in modules]
+        st = lambda k, j: torch.stack([p[k][j] for p in parts])
+        return cls(st(0, 0), st(0, 1), st(1, 0), st(1, 1), st(2, 0), st(2, 1), OUT_SOFTMAX, SAMPLE_CATEGORICAL, **kw)
+
+    @classmethod
+    def from_critic(cls, modules, **kw):
+        """N x CriticNN: input_layer -> hidden_layer1 -> output_layer, no activation (utils.py:22-53)."""
+        import torch
+        parts = [(_wt(m.input_layer), _wt(m.hidden_layer1), _wt(m.output_layer)) for m in modules]
+        st = lambda k, j: torch.stack([p[k][j] for p in parts])
+        return cls(st(0, 0), st(0, 1), st(1, 0), st(1, 1), st(2, 0), st(2, 1), OUT_IDENTITY, SAMPLE_NONE, **kw)
+
+    @classmethod
+    def from_normal_actor(cls, modules, **kw):
+        """N x NormalActorNN: the two heads (hidden_layer1 -> out_1 tanh, hidden_layer2 -> out_2 sigmoid,
+        utils.py:64-108) become one concatenated second layer and a block-diagonal output layer."""
+        import torch
+        w1, b1, w2, b2, w3, b3 = [], [], [], [], [], []
+        for m in modules:
+            a, ab = _wt(m.input_layer)
+            h1w, h1b = _wt(m.hidden_layer1); h2w, h2b = _wt(m.hidden_layer2)
+            o1w, o1b = _wt(m.out_1); o2w, o2b = _wt(m.out_2)
+            w1.append(a); b1.append(ab)
+            w2.append(torch.cat([h1w, h2w], dim=1)); b2.append(torch.cat([h1b, h2b]))
+            d = o1w.shape[1]
+            blk = torch.zeros(h1w.shape[1] + h2w.shape[1], 2 * d)
+            blk[:h1w.shape[1], :d] = o1w; blk[h1w.shape[1]:, d:] = o2w
+            w3.append(blk); b3.append(torch.cat([o1b, o2b]))
+        s = torch.stack
+        return cls(s(w1), s(b1), s(w2), s(b2), s(w3), s(b3), OUT_TANH_SIGMOID, SAMPLE_GAUSSIAN, **kw)
+
+    # ------------------------------------------------------------------ evaluation
+    def _run(self, z, want_out, sample, env_base=0):
+        torch = self._torch
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
+        E = z.shape[0]
+        if tuple(z.shape[:2]) != (E, self.n_agents) or z[0, 0].numel() != self.d_in:
+            raise ValueError(f"z must be [E,{self.n_agents},{self.d_in}], got {tuple(z.shape)}")
+        out = torch.empty(E, self.n_agents, self.nout, device=self.device) if want_out else None
+        act = idx = None
+        m = self._m
+        m.sample_kind = self.sample_kind if sample else SAMPLE_NONE
+        if sample:
+            act = torch.empty(E, self.n_agents, 2, device=self.device)
+            if self.sample_kind == SAMPLE_CATEGORICAL:
+                idx = torch.empty(E, self.n_agents, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self._lib.dronesim_mlp_forward(C.byref(m), z.data_ptr(), None if out is None else out.data_ptr(),
+                                                None if act is None else act.data_ptr(),
+                                                None if idx is None else idx.data_ptr(), self.seed, self.counter,
+                                                int(env_base), E, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        self._native.check(rc, "dronesim_mlp_forward")
+        if sample:
+            self.counter += 1
+        return out, act, idx
+
+    def forward(self, z):
+        """Post-activation outputs ``[E,N,nout]``: action probabilities / (mu_x, mu_y, var_x, var_y) / value."""
+        return self._run(z, True, False)[0]
+
+    def sample_action(self, z, env_base=0, return_outputs=False):
+        """Batched ``sample_action`` (utils.py:304-309 / 110-117): actions ``[E,N,2]`` ready for ``env.step``;
+        for the categorical policy also the chosen indices.  Every call advances the Philox counter."""
+        out, act, idx = self._run(z, return_outputs, True, env_base)
+        return (act, idx, out) if return_outputs else (act, idx)

@@ -262,7 +262,42 @@ def gen_controllers():
     print("controllers:", len(data) // 4, "geometries x 8 states")
 
 
+def gen_policies():
+    """Forward outputs of the reference's own per-agent networks (utils.py:14-117, 255-302) with their
+    weights, for the batched policy kernel.  Weights are stored [in, out] per agent."""
+    import torch
+    from utils import CriticNN, DiscreteSoftmaxNN, NormalActorNN
+    torch.manual_seed(11)
+    N, B, d_in = 2, 9, 6
+    x = (torch.rand(B, N, d_in) * 6 - 3)
+    data = {"x": x.numpy().astype(np.float64)}
+
+    def grab(prefix, mods, layers):
+        for li, name in enumerate(layers):
+            data[f"{prefix}_w{li}"] = np.stack([getattr(m, name).weight.detach().numpy().T for m in mods])   # float32
+            data[f"{prefix}_b{li}"] = np.stack([getattr(m, name).bias.detach().numpy() for m in mods])
+
+    soft = [DiscreteSoftmaxNN(d_in, lr=1e-3, n_actions=16) for _ in range(N)]
+    grab("soft", soft, ["input_layer", "hidden_layer1", "out_1"])
+    data["soft_out"] = np.stack([np.stack([soft[i].forward(x[b, i]).detach().numpy() for i in range(N)])
+                                 for b in range(B)]).astype(np.float64)
+    data["soft_action_list"] = soft[0].action_list
+    norm = [NormalActorNN(d_in, lr=1e-3, dim_action=2) for _ in range(N)]
+    grab("norm", norm, ["input_layer", "hidden_layer1", "hidden_layer2", "out_1", "out_2"])
+    data["norm_out"] = np.stack([np.stack([np.concatenate([t.detach().numpy() for t in norm[i].forward(x[b, i])])
+                                           for i in range(N)]) for b in range(B)]).astype(np.float64)
+    crit = [CriticNN(d_in, output_size=1) for _ in range(N)]
+    grab("crit", crit, ["input_layer", "hidden_layer1", "output_layer"])
+    data["crit_out"] = np.stack([np.stack([crit[i].forward(x[b, i]).detach().numpy() for i in range(N)])
+                                 for b in range(B)]).astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, "policies.npz"), **data, **{f"meta_{a}": b for a, b in META.items()})
+    print("policies:", {k: v.shape for k, v in data.items() if k.endswith("_out")})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "policies":
+        gen_policies()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "controllers":
         gen_controllers()
         return
@@ -296,6 +331,7 @@ def main():
     gen_single_step("n256_c2", 256, 256, 2, True, np.ones(256) * 2.5, 3, 60.0, rng)
     gen_episode()
     gen_controllers()
+    gen_policies()
 
 
 if __name__ == "__main__":

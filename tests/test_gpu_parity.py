@@ -476,3 +476,100 @@ def test_returns_and_advantage(torch):
     assert torch.equal(out["nbr_idx_pre"][1:], out["nbr_idx"][:-1]) and torch.equal(out["z_pre"][1:], out["z"][:-1])
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mc_returns(torch.zeros(2, 2, 2), 0.9)
+
+
+# ------------------------------------------------------------------------------- batched policies
+class _L:      # minimal stand-in exposing .weight [out,in] / .bias like torch.nn.Linear
+    def __init__(self, w_in_out, b):
+        import torch
+        self.weight = torch.tensor(np.asarray(w_in_out).T.copy(), dtype=torch.float32)
+        self.bias = torch.tensor(np.asarray(b), dtype=torch.float32)
+
+
+class _M:
+    pass
+
+
+def _modules(fx, prefix, names):
+    mods = []
+    for i in range(fx[f"{prefix}_w0"].shape[0]):
+        m = _M()
+        for li, nm in enumerate(names):
+            setattr(m, nm, _L(fx[f"{prefix}_w{li}"][i], fx[f"{prefix}_b{li}"][i]))
+        mods.append(m)
+    return mods
+
+
+def test_batched_policies_match_reference_networks(torch):
+    """DiscreteSoftmaxNN / NormalActorNN / CriticNN forward outputs of the reference's own modules
+    (utils.py:14-117, 255-302) reproduced by the batched matrix-core kernel in exact float32."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    fx = H.load("policies.npz")
+    x = torch.tensor(fx["x"], dtype=torch.float32, device="cuda:0")
+    soft = BatchedMLP.from_discrete_softmax(_modules(fx, "soft", ["input_layer", "hidden_layer1", "out_1"]))
+    H.assert_close(host(soft.forward(x)), fx["soft_out"], "softmax probs")
+    norm = BatchedMLP.from_normal_actor(_modules(fx, "norm", ["input_layer", "hidden_layer1", "hidden_layer2", "out_1", "out_2"]))
+    H.assert_close(host(norm.forward(x)), fx["norm_out"], "mu, sigma^2")
+    crit = BatchedMLP.from_critic(_modules(fx, "crit", ["input_layer", "hidden_layer1", "output_layer"]))
+    H.assert_close(host(crit.forward(x)), fx["crit_out"], "critic value")
+    # sampling: categorical actions are the reference's unit vectors (utils.py:262-269)
+    act, idx = soft.sample_action(x)
+    assert idx.dtype == torch.int32 and int(idx.min()) >= 0 and int(idx.max()) < 16
+    H.assert_close(host(act), fx["soft_action_list"][host(idx)], "unit-circle actions")
+
+
+def test_batched_policy_large_batch_and_sampling_statistics(torch):
+    """Random networks at rollout size (E not a multiple of the 64-row tile) vs a float64 torch reference;
+    sampled indices follow the probabilities; Gaussian samples follow (mu, sqrt(var)); streams are
+    reproducible per (seed, counter) and shard-invariant (env_base)."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    g = torch.Generator().manual_seed(3)
+    N, E, d = 5, 1000, 6
+
+    def net(h1, h2, nout, scale):
+        r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * scale
+        return r(N, d, h1), r(N, h1) , r(N, h1, h2) * 0.2, r(N, h2), r(N, h2, nout) * 0.2, r(N, nout)
+
+    def ref(x, w, act):
+        w1, b1, w2, b2, w3, b3 = [t.double() for t in w]
+        xd = x.double().cpu()
+        h = torch.relu(torch.einsum("end,ndh->enh", xd, w1) + b1)
+        h = torch.relu(torch.einsum("enh,nhk->enk", h, w2) + b2)
+        y = torch.einsum("enk,nko->eno", h, w3) + b3
+        return act(y).numpy()
+
+    x = torch.rand(E, N, d, generator=g) * 4 - 2
+    w = net(300, 300, 16, 0.4)
+    soft = BatchedMLP(*w, out_kind=1, sample_kind=1, seed=9)
+    p = host(soft.forward(x.cuda()))
+    H.assert_close(p, ref(x, w, lambda y: torch.softmax(y, -1)), "softmax 300x300x16")
+    assert np.allclose(p.sum(-1), 1.0, atol=1e-5)
+    # frequencies of 400 draws of one fixed observation row vs its probabilities
+    xr = x[:1].expand(E, N, d).contiguous().cuda()
+    counts = np.zeros((N, 16))
+    for _ in range(4):
+        act, idx = soft.sample_action(xr)
+        for i in range(N):
+            counts[i] += np.bincount(host(idx)[:, i], minlength=16)
+    freq = counts / counts.sum(1, keepdims=True)
+    assert np.abs(freq - p[0]).max() < 0.03                                  # 4000 draws: sigma <= 0.008
+    soft2 = BatchedMLP(*w, out_kind=1, sample_kind=1, seed=9)
+    a1, i1 = soft2.sample_action(xr); soft2.counter = 0; a2, i2 = soft2.sample_action(xr)
+    assert torch.equal(i1, i2) and torch.equal(a1, a2)
+    soft2.counter = 0; _, i3 = soft2.sample_action(xr[100:], env_base=100)
+    assert torch.equal(i3, i1[100:])                                           # shard invariance
+    # Gaussian policy 6 -> 400 -> 400 -> 4
+    wn = net(400, 400, 4, 0.3)
+    tanh_sig = lambda y: torch.cat([torch.tanh(y[..., :2]), torch.sigmoid(y[..., 2:])], -1)
+    norm = BatchedMLP(*wn, out_kind=2, sample_kind=2, seed=4)
+    ms = host(norm.forward(x.cuda()))
+    H.assert_close(ms, ref(x, wn, tanh_sig), "mu/var 400x400x4")
+    xs = x[:1].expand(4000, N, d).contiguous().cuda()
+    act, idx = norm.sample_action(xs)
+    assert idx is None and tuple(act.shape) == (4000, N, 2)
+    a = host(act)
+    assert np.abs(a.mean(0) - ms[0, :, :2]).max() < 0.06 and np.abs(a.std(0) - np.sqrt(ms[0, :, 2:])).max() < 0.05
+    # critic 6 -> 200 -> 200 -> 1
+    wc = net(200, 200, 1, 0.5)
+    crit = BatchedMLP(*wc, out_kind=0, sample_kind=0)
+    H.assert_close(host(crit.forward(x.cuda())), ref(x, wc, lambda y: y), "critic 200x200x1")
