@@ -14,11 +14,12 @@
 // Arithmetic: exact float32 on the matrix cores -- v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain
 // (no reduced precision), so results match a float32 torch reference to round-off.
 // Decomposition: grid = (ceil(E/64), N): one workgroup = 64 env rows of ONE agent, 4 waves.
-//   wave w owns row half (w & 1) and every second 32-column chunk of the hidden layers.
+//   wave w owns every fourth 32-column chunk of the hidden layers for all 64 rows (two 32x32
+//   accumulators that share every B fragment).
 //   layer 1: A = x tile (LDS), B = W1 (global/L2)            -> h1 tile in LDS [64][h1+1]
-//   layer 2 chunk (32 columns): A = h1 (LDS), B = W2          -> relu -> per-wave LDS staging [32][33]
+//   layer 2 chunk (32 columns): A = h1 (LDS), B = W2          -> relu -> per-wave LDS staging [64][33]
 //   layer 3 partial: A = staged chunk, B = W3 rows of the chunk -> accumulated in registers
-//   partials of the two chunk-parities are summed through LDS, then activation + sampling.
+//   the four waves' partials are summed through LDS, then activation + sampling.
 // LDS row strides are odd (h1+1, 33) so the 32-row fragment reads are bank-conflict free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -44,32 +45,58 @@ struct MArgs {
 // C/D layout of v_mfma_f32_32x32x2_f32: element reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31)
 __device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// acc += A[32 x K] * B[K x 32]:  A row-major in LDS (lda floats per row), B row-major in global (ldb floats
-// per row); B columns >= ncols_valid and k >= K read as zero.
-__device__ __forceinline__ f32x16 tile_gemm(f32x16 acc, const float *A, int lda, const float *__restrict__ B, int ldb,
-                                            int K, int ncols_valid, int lane)
+// (acc0, acc1) += A[64 x K] * B[K x 32] for the two 32-row halves of A, sharing every B fragment.
+// A row-major in LDS (lda floats per row, odd stride -> conflict-free), B row-major in global / L2 (ldb
+// floats per row); B columns >= ncols_valid and k >= K read as zero.  Operand loads of the next 8 k-steps
+// are issued before the 16 MFMAs of the current ones (software pipelining: one wave per SIMD has nobody
+// else to hide the L2 latency behind).
+constexpr int kU = 8;                  // k-steps (of 2) per pipeline stage
+
+struct Frag { float b[kU], a0[kU], a1[kU]; };
+
+// branch-free: every k of the stage is < K and the column index is already clamped
+__device__ __forceinline__ void load_frag(Frag &f, const float *Arow0, const float *Arow1,
+                                          const float *__restrict__ Bcol, int ldb, int kbase)
+{
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+        const int k = kbase + 2 * u;
+        f.b[u] = Bcol[(size_t)k * ldb];
+        f.a0[u] = Arow0[k];
+        f.a1[u] = Arow1[k];
+    }
+}
+
+__device__ __forceinline__ void tile_gemm2(f32x16 &acc0, f32x16 &acc1, const float *A, int lda,
+                                           const float *__restrict__ B, int ldb, int K, int ncols_valid, int lane)
 {
     const int ar = lane & 31, kk = lane >> 5;
-    const bool colok = ar < ncols_valid;
-    int k0 = 0;
-    for (; k0 + 8 <= K; k0 += 8) {                         // 4 MFMAs per trip, their 4+4 operand loads in flight
-        float av[4], bv[4];
+    // columns beyond the matrix read a clamped (valid) column; their results are never stored
+    const float *Bcol = B + min(ar, ncols_valid - 1);
+    const float *Arow0 = A + ar * lda, *Arow1 = A + (ar + 32) * lda;
+    const int Kmain = K - K % (2 * kU);                    // whole pipeline stages, no bounds checks inside
+    if (Kmain > 0) {
+        Frag cur, nxt;
+        load_frag(cur, Arow0, Arow1, Bcol, ldb, kk);
+        for (int k0 = 0; k0 < Kmain; k0 += 2 * kU) {
+            const bool more = k0 + 2 * kU < Kmain;         // wave-uniform
+            if (more) load_frag(nxt, Arow0, Arow1, Bcol, ldb, k0 + 2 * kU + kk);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = k0 + 2 * u + kk;
-            av[u] = A[ar * lda + k];
-            bv[u] = colok ? B[(size_t)k * ldb + ar] : 0.0f;
+            for (int u = 0; u < kU; ++u) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0[u], cur.b[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1[u], cur.b[u], acc1, 0, 0, 0);
+            }
+            if (more) cur = nxt;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     }
-    for (; k0 < K; k0 += 2) {
+    for (int k0 = Kmain; k0 < K; k0 += 2) {                // tail (K not a multiple of 16)
         const int k = k0 + kk;
-        const float av = k < K ? A[ar * lda + k] : 0.0f;
-        const float bv = (colok && k < K) ? B[(size_t)k * ldb + ar] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        const bool kok = k < K;
+        const float bv = kok ? Bcol[(size_t)k * ldb] : 0.0f;
+        const float a0 = kok ? Arow0[k] : 0.0f, a1 = kok ? Arow1[k] : 0.0f;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
     }
-    return acc;
 }
 
 __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
@@ -82,8 +109,8 @@ __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
     const int ldx = a.d_in + 1, ld1 = a.h1 + 1;
     float *sx = reinterpret_cast<float *>(smem);                 // [64][d_in+1]
     float *sh1 = sx + kRows * ldx;                               // [64][h1+1]
-    float *sst = sh1 + kRows * ld1;                              // [4 waves][32][33] layer-2 chunk staging
-    float *spart = sst + 4 * 32 * 33;                            // [4 waves][32][33] layer-3 partials
+    float *sst = sh1 + kRows * ld1;                              // [4 waves][64][33] layer-2 chunk staging,
+                                                                 // reused for the layer-3 partials
     const float *w1 = a.w1 + (size_t)agent * a.d_in * a.h1, *b1 = a.b1 + (size_t)agent * a.h1;
     const float *w2 = a.w2 + (size_t)agent * a.h1 * a.h2, *b2 = a.b2 + (size_t)agent * a.h2;
     const float *w3 = a.w3 + (size_t)agent * a.h2 * a.nout, *b3 = a.b3 + (size_t)agent * a.nout;
@@ -96,53 +123,66 @@ __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
     }
     __syncthreads();
 
-    const int rh = wave & 1, cp = wave >> 1;                     // row half, chunk parity of this wave
     const int col = lane & 31;
-    // ---- layer 1
-    for (int c0 = cp * 32; c0 < a.h1; c0 += 64) {
-        f32x16 acc = {0};
-        acc = tile_gemm(acc, sx + rh * 32 * ldx, ldx, w1 + c0, a.h1, a.d_in, a.h1 - c0, lane);
+    // ---- layer 1: wave w owns column chunks w, w+4, ... (all 64 rows)
+    for (int c0 = wave * 32; c0 < a.h1; c0 += 128) {
+        f32x16 acc0 = {0}, acc1 = {0};
+        tile_gemm2(acc0, acc1, sx, ldx, w1 + c0, a.h1, a.d_in, a.h1 - c0, lane);
         const bool ok = c0 + col < a.h1;
         const float bias = ok ? b1[c0 + col] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (ok) sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc[r] + bias, 0.0f);
+            if (ok) {
+                sh1[cd_row(r, lane) * ld1 + c0 + col] = fmaxf(acc0[r] + bias, 0.0f);
+                sh1[(32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc1[r] + bias, 0.0f);
+            }
     }
     __syncthreads();
 
     // ---- layers 2 + 3 fused over this wave's column chunks
-    f32x16 acc3 = {0};
-    float *st = sst + wave * 32 * 33;
-    for (int c0 = cp * 32; c0 < a.h2; c0 += 64) {
-        f32x16 acc = {0};
-        acc = tile_gemm(acc, sh1 + rh * 32 * ld1, ld1, w2 + c0, a.h2, a.h1, a.h2 - c0, lane);
+    f32x16 y0 = {0}, y1 = {0};
+    float *st = sst + wave * 64 * 33;
+    for (int c0 = wave * 32; c0 < a.h2; c0 += 128) {
+        f32x16 acc0 = {0}, acc1 = {0};
+        tile_gemm2(acc0, acc1, sh1, ld1, w2 + c0, a.h2, a.h1, a.h2 - c0, lane);
         const bool ok = c0 + col < a.h2;
         const float bias = ok ? b2[c0 + col] : 0.0f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = ok ? fmaxf(acc[r] + bias, 0.0f) : 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            st[cd_row(r, lane) * 33 + col] = ok ? fmaxf(acc0[r] + bias, 0.0f) : 0.0f;
+            st[(32 + cd_row(r, lane)) * 33 + col] = ok ? fmaxf(acc1[r] + bias, 0.0f) : 0.0f;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int kc = min(32, a.h2 - c0);
-        acc3 = tile_gemm(acc3, st, 33, w3 + (size_t)c0 * a.nout, a.nout, kc, a.nout, lane);
+        tile_gemm2(y0, y1, st, 33, w3 + (size_t)c0 * a.nout, a.nout, kc, a.nout, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    float *part = spart + wave * 32 * 33;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) part[cd_row(r, lane) * 33 + col] = acc3[r];
+    for (int r = 0; r < 16; ++r) {                               // this wave's partial outputs
+        st[cd_row(r, lane) * 33 + col] = y0[r];
+        st[(32 + cd_row(r, lane)) * 33 + col] = y1[r];
+    }
     __syncthreads();
 
     // ---- output activation + sampling: one thread per env row
     if (tid < kRows) {
         const int e = e0 + tid;
         if (e >= a.E) return;
-        const int rhh = tid >> 5, rr = tid & 31;
-        const float *p0 = spart + (rhh + 0) * 32 * 33 + rr * 33, *p1 = spart + (rhh + 2) * 32 * 33 + rr * 33;
         float y[kMaxOut];
         const int nout = a.nout;
 #pragma unroll
-        for (int j = 0; j < kMaxOut; ++j) y[j] = j < nout ? p0[j] + p1[j] + b3[j] : 0.0f;
+        for (int j = 0; j < kMaxOut; ++j) {
+            float v = 0.0f;
+            if (j < nout) {
+                v = b3[j];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += sst[(w * 64 + tid) * 33 + j];
+            }
+            y[j] = v;
+        }
         if (a.out_kind == 1) {                                   // softmax (utils.py:286, dim = 0 of one sample)
             float m = -__builtin_inff();
 #pragma unroll
@@ -223,7 +263,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32);
     a.ctr2 = (uint32_t)counter; a.ctr3 = (uint32_t)(counter >> 32);
     a.env_base = env_base;
-    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + 2 * 4 * 32 * 33);
+    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + 4 * 64 * 33);
     static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
     if (!big_lds_enabled) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
