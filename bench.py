@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
+    ap.add_argument("--policy", default="random", choices=["random", "softmax16", "gaussian"],
+                    help="action source: pre-generated U(-1,1) actions (the graded workload) or a batched per-agent "
+                         "policy evaluated on the env's observation every step (BASELINE configs[4] uses 'gaussian')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -121,8 +124,21 @@ def main():
     pool = torch.rand(T_ep, E, N, 2, device=dev, generator=g) * 2 - 1
     stats = EpisodeStats(dev)                       # what train_problem.py:98-100 logs, kept on device
 
+    policy = None
+    if args.policy != "random":                     # random-init per-agent networks of the reference's shapes
+        from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+        gp = torch.Generator().manual_seed(4321)
+        rw = lambda *sh: (torch.rand(*sh, generator=gp) * 2 - 1) * 0.2
+        h, nout, ok, sk = (300, 16, 1, 1) if args.policy == "softmax16" else (400, 4, 2, 2)   # utils.py:255-302 / 55-108
+        policy = BatchedMLP(rw(N, 6, h), rw(N, h), rw(N, h, h), rw(N, h), rw(N, h, nout), rw(N, nout), ok, sk,
+                            device=dev, seed=1234)
+
     def one_step(s):
-        res = env.step(pool[s % T_ep])
+        if policy is None:
+            res = env.step(pool[s % T_ep])
+        else:                                       # obs -> sample_action -> step (SAC_agents.py:170-180, train_problem.py:91-94)
+            act, _ = policy.sample_action(env.z, env=env)
+            res = env.step(act)
         if (s + 1) % T_ep == 0:                     # episode end: sample the statistic, reset (train_problem.py:132)
             stats.add_step(res.rewards, res.true_rewards, res.n_collisions)
             env.reset(renew_obstacles=False)
@@ -215,6 +231,8 @@ def main():
             "config": {"workload": label, "n_agents": N, "envs_per_gpu": e_gpu, "n_envs_total": E_global,
                        "grid": G, "delta": delta, "k_closest": 2, "simplify_zstate": True,
                        "launch": "hipGraph replay (200 steps + reset per graph)" if graph is not None else "eager",
+                       "actions": "pre-generated U(-1,1)^2, resident in HBM" if policy is None else
+                                  f"batched per-agent {args.policy} policy (random-init, exact-f32 MFMA) on the observation",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -151,7 +151,9 @@ int dronesim_advantage(const float *G, const float *V, const int32_t *nbr_idx, c
  * Weights are stacked per agent, "in x out" row-major: w1 [N][d_in][h1], b1 [N][h1], w2 [N][h1][h2],
  * b2 [N][h2], w3 [N][h2][nout], b3 [N][nout] (torch Linear stores [out][in]: transpose when importing).
  * out [E][N][nout] (post-activation, may be NULL), act [E][N][2] and act_idx [E][N] (may be NULL).
- * Random stream: Philox4x32-10 keyed by (seed, counter, env_base + e, agent).                       */
+ * Random stream: Philox4x32-10 keyed by (seed, env_base + e, agent, counter.lo + t[e],
+ * counter.hi + episode[e]); t / episode (int32 [E], device, may be NULL) are the env's own step and
+ * episode counters, so a captured hipGraph draws fresh numbers on every replay.                      */
 typedef struct DroneMlp {
     int32_t N, d_in, h1, h2, nout;
     int32_t out_kind;       /* 0 identity, 1 softmax, 2 tanh(first half) + sigmoid(second half) */
@@ -160,7 +162,8 @@ typedef struct DroneMlp {
     const float *w1, *b1, *w2, *b2, *w3, *b3;
 } DroneMlp;
 int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,
-                         uint64_t seed, uint64_t counter, int64_t env_base, int E, void *stream);
+                         uint64_t seed, uint64_t counter, int64_t env_base,
+                         const int32_t *t, const int32_t *episode, int E, void *stream);
 
 const char *dronesim_last_error(void);
 const char *dronesim_error_string(int code);

@@ -74,7 +74,7 @@ def lib():
     L.dronesim_returns.argtypes = [vp, vp, f32, vp, i32, i32, i32, vp]
     L.dronesim_advantage.argtypes = [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, vp]
     L.dronesim_returns.restype = L.dronesim_advantage.restype = C.c_int
-    L.dronesim_mlp_forward.argtypes = [C.POINTER(DroneMlp), vp, vp, vp, vp, u64, u64, i64, i32, vp]
+    L.dronesim_mlp_forward.argtypes = [C.POINTER(DroneMlp), vp, vp, vp, vp, u64, u64, i64, vp, vp, i32, vp]
     L.dronesim_mlp_forward.restype = C.c_int
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
     for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset",

@@ -40,6 +40,7 @@ struct MArgs {
     int *act_idx;
     uint32_t key0, key1, ctr2, ctr3;
     long long env_base;
+    const int *t_dev, *episode_dev;      // optional per-env stream ids kept on the device (graph-replay safe)
 };
 
 // C/D layout of v_mfma_f32_32x32x2_f32: element reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31)
@@ -206,7 +207,9 @@ __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
         }
         if (a.sample_kind != 0) {
             uint32_t rnd[4];
-            philox4x32_10((uint32_t)agent, (uint32_t)(a.env_base + e), a.ctr2, a.ctr3, a.key0, a.key1, rnd);
+            const uint32_t c2 = a.ctr2 + (a.t_dev ? (uint32_t)a.t_dev[e] : 0u);
+            const uint32_t c3 = a.ctr3 + (a.episode_dev ? (uint32_t)a.episode_dev[e] : 0u);
+            philox4x32_10((uint32_t)agent, (uint32_t)(a.env_base + e), c2, c3, a.key0, a.key1, rnd);
             if (a.sample_kind == 1) {                            // categorical -> unit vector (utils.py:262-269, 304-309)
                 const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
                 float cdf = 0.0f;
@@ -241,7 +244,8 @@ __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
 }   // namespace
 
 extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,
-                                    uint64_t seed, uint64_t counter, int64_t env_base, int E, void *stream)
+                                    uint64_t seed, uint64_t counter, int64_t env_base,
+                                    const int32_t *t, const int32_t *episode, int E, void *stream)
 {
     if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL argument");
     if (m->N < 1 || m->d_in < 1 || m->d_in > 64 || m->h1 < 1 || m->h1 > 512 || m->h2 < 1 || m->h2 > 512 ||
@@ -262,7 +266,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     a.out = out; a.act = act; a.act_idx = act_idx;
     a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32);
     a.ctr2 = (uint32_t)counter; a.ctr3 = (uint32_t)(counter >> 32);
-    a.env_base = env_base;
+    a.env_base = env_base; a.t_dev = t; a.episode_dev = episode;
     const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + 4 * 64 * 33);
     static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
     if (!big_lds_enabled) {

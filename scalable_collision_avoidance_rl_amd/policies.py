@@ -87,7 +87,7 @@ class BatchedMLP:
         return cls(s(w1), s(b1), s(w2), s(b2), s(w3), s(b3), OUT_TANH_SIGMOID, SAMPLE_GAUSSIAN, **kw)
 
     # ------------------------------------------------------------------ evaluation
-    def _run(self, z, want_out, sample, env_base=0):
+    def _run(self, z, want_out, sample, env_base=0, env=None):
         torch = self._torch
         z = z.to(device=self.device, dtype=torch.float32).contiguous()
         E = z.shape[0]
@@ -105,9 +105,11 @@ class BatchedMLP:
             rc = self._lib.dronesim_mlp_forward(C.byref(m), z.data_ptr(), None if out is None else out.data_ptr(),
                                                 None if act is None else act.data_ptr(),
                                                 None if idx is None else idx.data_ptr(), self.seed, self.counter,
-                                                int(env_base), E, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                                int(env_base), None if env is None else env.t.data_ptr(),
+                                                None if env is None else env.episode.data_ptr(), E,
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream))
         self._native.check(rc, "dronesim_mlp_forward")
-        if sample:
+        if sample and env is None:
             self.counter += 1
         return out, act, idx
 
@@ -115,8 +117,12 @@ class BatchedMLP:
         """Post-activation outputs ``[E,N,nout]``: action probabilities / (mu_x, mu_y, var_x, var_y) / value."""
         return self._run(z, True, False)[0]
 
-    def sample_action(self, z, env_base=0, return_outputs=False):
+    def sample_action(self, z, env_base=0, return_outputs=False, env=None):
         """Batched ``sample_action`` (utils.py:304-309 / 110-117): actions ``[E,N,2]`` ready for ``env.step``;
-        for the categorical policy also the chosen indices.  Every call advances the Philox counter."""
-        out, act, idx = self._run(z, return_outputs, True, env_base)
+        for the categorical policy also the chosen indices.  Every call advances the Philox counter; with
+        ``env=`` (a batched `drones`) the stream is keyed by the env's own device-side ``t`` / ``episode``
+        counters instead, which keeps a captured hipGraph drawing fresh numbers on every replay."""
+        if env is not None:
+            env_base = env.env_lo
+        out, act, idx = self._run(z, return_outputs, True, env_base, env)
         return (act, idx, out) if return_outputs else (act, idx)

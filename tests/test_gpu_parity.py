@@ -573,3 +573,30 @@ def test_batched_policy_large_batch_and_sampling_statistics(torch):
     wc = net(200, 200, 1, 0.5)
     crit = BatchedMLP(*wc, out_kind=0, sample_kind=0)
     H.assert_close(host(crit.forward(x.cuda())), ref(x, wc, lambda y: y), "critic 200x200x1")
+
+
+def test_policy_rollout_loop_under_graph_replay(torch):
+    """obs -> sample_action -> step captured in a hipGraph: the sampling stream is keyed by the env's
+    device-side t / episode counters, so every replayed step draws new actions."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    N, E = 5, 64
+    env = make_env(N, 5.0, 2, 2, np.ones(N), E, seed=2)
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * 0.3
+    pol = BatchedMLP(r(N, 6, 300), r(N, 300), r(N, 300, 300), r(N, 300), r(N, 300, 16), r(N, 16), 1, 1, seed=5)
+    idx_log = torch.zeros(3, E, N, dtype=torch.int32, device="cuda:0")
+    step_no = [0]
+
+    def body():
+        act, idx = pol.sample_action(env.z, env=env)
+        env.step(act)
+        return idx
+    body(); torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        idx = body()
+    seen = []
+    for _ in range(3):
+        graph.replay(); torch.cuda.synchronize(); seen.append(idx.clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    assert int(env.t[0]) == 4                                     # 1 eager step + 3 replays (capture does not execute)

@@ -52,7 +52,7 @@ for spec in (sys.argv[1:] or ["c3", "c2", "c5"]):
         line = f"{spec} {kind:>9}: policy {us:8.1f} us/step = {flops/us/1e6:6.1f} TFLOP/s f32"
         if pol.sample_kind:
             def loop():
-                act, _ = pol.sample_action(env.z)
+                act, _ = pol.sample_action(env.z, env=env)
                 env.step(act)
             us2 = timeit(loop)
             line += f" | obs->policy->step {us2:8.1f} us/step = {N*E/us2*1e6:.3e} agent-steps/s"
