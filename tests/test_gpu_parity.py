@@ -600,3 +600,82 @@ def test_policy_rollout_loop_under_graph_replay(torch):
         graph.replay(); torch.cuda.synchronize(); seen.append(idx.clone())
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
     assert int(env.t[0]) == 4                                     # 1 eager step + 3 replays (capture does not execute)
+
+
+# ------------------------------------------------------------------------------- shape fuzzing / invariances
+def test_shape_fuzz_against_oracle(torch):
+    """40 seeded random shapes across the kernel variants (k = 1..8, packed / symmetric / workgroup-per-env
+    geometries, c = 2 / 5, uniform / heterogeneous / default Delta, ragged E): step + observe vs the oracle."""
+    rng = np.random.default_rng(2024)
+    tried = set()
+    for it in range(40):
+        N = int(rng.choice([2, 3, 4, 6, 7, 9, 16, 21, 32, 33, 48, 63, 64, 65, 96, 128, 200]))
+        k = int(rng.integers(1, min(N - 1, 8) + 1))
+        c = int(rng.choice([2, 2, 5]))
+        G = float(max(6.0, 0.45 * N + 2 * rng.random()))                 # keeps d_hat > 0 and Delta effective
+        mode = rng.choice(["uniform", "hetero", "none"])
+        E = int(rng.integers(1, 70))
+        from scalable_collision_avoidance_rl_amd import formation_O
+        d_hat = formation_O(N, [G, G])[1]
+        if d_hat.min() <= 0.05:
+            continue
+        if mode == "uniform":
+            deltas = np.ones(N) * float(rng.uniform(0.2, 0.95)) * d_hat.min()
+        elif mode == "hetero":
+            deltas = rng.uniform(0.1, 1.3, N) * d_hat.min()
+        else:
+            deltas = None
+        tried.add((N <= 64, N == 64, c, mode))
+        env = make_env(N, G, k, c, deltas, E, seed=it)
+        orc = Oracle(N, [G, G], k, deltas, c == 2, threads=4)
+        box = float(rng.uniform(0.3, 0.9)) * G
+        pos0 = (G / 2 + (rng.random((E, N, 2)) - 0.5) * box).astype(np.float32)
+        act = rng.uniform(-1, 1, (E, N, 2)).astype(np.float32)
+        t0 = rng.integers(0, 205, E).astype(np.int32)
+        env.set_state(pos0, None, t0)
+        res = env.step(torch.tensor(act, device="cuda:0"))
+        torch.cuda.synchronize()
+        p1 = host(env.pos).astype(np.float64)
+        ref = orc.observe(p1, act.astype(np.float64))
+        safe = orc.margins(p1) > H.MARGIN
+        if not safe.any():
+            continue
+        tag = f"fuzz#{it} N={N} k={k} c={c} {mode} E={E} "
+        check_outputs(env, res, ref, safe, c, None, tag)
+        xF = orc.xF[None]
+        all_in = (np.linalg.norm(xF - p1, axis=-1) <= 0.2).all(-1)
+        np.testing.assert_array_equal(host(res.finished)[safe].astype(bool), (all_in | (t0 >= 199))[safe])
+        np.testing.assert_array_equal(host(env.t), t0 + 1)
+    assert len(tried) >= 10
+
+
+def test_invariances(torch):
+    """Size-independent properties at C3 size: splitting the env axis changes nothing (bit-exact);
+    a common translation of all agents leaves collisions, neighbour lists, relative z rows and the
+    barrier part of the reward unchanged (positions chosen on a 2^-7 grid so translation is exact in f32)."""
+    N, G, E = 64, 28.0, 4096
+    rng = np.random.default_rng(8)
+    pos = (np.round((G / 2 + (rng.random((E, N, 2)) - 0.5) * 20) * 128) / 128).astype(np.float32)
+    act = torch.zeros(E, N, 2, device="cuda:0")
+    full = make_env(N, G, 2, 2, np.ones(N), E)
+    full.set_state(pos); full.step(act)
+    for lo, hi in [(0, 1), (1, 1000), (1000, 4096)]:
+        part = make_env(N, G, 2, 2, np.ones(N), hi - lo)
+        part.set_state(pos[lo:hi]); part.step(act[lo:hi])
+        for name in ("reward", "true_reward", "z", "nbr_idx", "n_coll", "done", "pos"):
+            assert torch.equal(getattr(part, name), getattr(full, name)[lo:hi]), name
+    shift = np.array([1.5, -2.25], np.float32)
+    moved = make_env(N, G, 2, 2, np.ones(N), E)
+    moved.set_state(pos + shift); moved.step(act)
+    assert torch.equal(moved.n_coll, full.n_coll) and torch.equal(moved.nbr_idx, full.nbr_idx)
+    real = (full.nbr_idx >= 0)[..., 1:]                                   # neighbour rows (not ghosts) are differences
+    zf = full.z.view(E, N, 3, 2)[:, :, 1:][real]; zm = moved.z.view(E, N, 3, 2)[:, :, 1:][real]
+    assert torch.equal(zf, zm)
+    xF = torch.tensor(formation_xF(N, G), device="cuda:0")
+    barrier = lambda e: e.reward + 0.1 * ((xF[None] - e.pos) ** 2).sum(-1)
+    assert float((barrier(full) - barrier(moved)).abs().max()) < 2e-3     # cancellation of two O(30) terms in f32
+
+
+def formation_xF(N, G):
+    from scalable_collision_avoidance_rl_amd import formation_O
+    return formation_O(N, [G, G])[0].reshape(N, 2).astype(np.float32)
