@@ -160,6 +160,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
 {
     constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
     constexpr bool SYM = GEO == kSym64;
+    constexpr bool SYMB = (GEO == kBlock256 || GEO == kBlock1024) && !FAR;   // pair-once scan for N > 64
     static_assert(!(SYM && FAR), "the symmetric filter assumes far agents never matter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TRACE_MARK(0);
@@ -236,6 +237,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
     unsigned *stage_z = sstage + (size_t)wave * kWave * (kZRow + kNRow);                   // [64][kZRow]
     unsigned *stage_n = stage_z + kWave * kZRow;                                           // [64][kNRow]
     float2 *sconst = sconst_all + (WL ? (size_t)wave * (N + (N & 1)) : 0);
+    // SYMB: per agent, one bit per backward offset r = 1..N/2 set by the partner that scanned the pair
+    const int nbw = (N / 2 + 31) >> 5;
+    unsigned *sback = sstage + (size_t)nwaves * kWave * (kZRow + kNRow);                   // [N][nbw]
 
     if (WL) {
         if ((int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;
@@ -243,9 +247,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
     } else {
         if (tid < 2) sred[tid] = 0;
         for (int s = tid; s < N; s += blockDim.x) sconst[s] = make_float2(a.delta[s], a.radius[s]);
+        if (SYMB) for (int s = tid; s < N * nbw; s += blockDim.x) sback[s] = 0u;
     }
 
-    const float reach = SYM ? a.reach_max : dhat + li + a.radius_max;
+    const float reach = (SYM || SYMB) ? a.reach_max : dhat + li + a.radius_max;
     const float thr = reach * reach * 1.000001f;             // early-out radius^2 (conservative)
     const float log2_dhat = __builtin_amdgcn_logf(dhat);     // v_log_f32 = log2
     float2 *spos_env = spos + (size_t)slot * 2 * stride;     // S0 of this lane's env
@@ -277,21 +282,44 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
 
         float zrx[K + 1], zry[K + 1];
         int nbv[K + 1];
-        if (valid) {
-            float s_all = 0.f, s_msk = 0.f;
-            int ncoll = 0;
-            unsigned long long list[K + 1];
+        float s_all = 0.f, s_msk = 0.f;
+        int ncoll = 0;
+        unsigned long long list[K + 1];
 #pragma unroll
-            for (int s = 0; s <= K; ++s) list[s] = ~0ull;
-            // self entry: d_ii = min(-2 l_i, dhat_i), ratio 1 -> log 0, never a collision (:323-325)
-            const float dii = fminf(-li - li, dhat);
-            list[0] = nbr_key(dii, agent);
-            int in_range = ((dii <= delta_i) ? 1 : 0) - 1;    // :346 (N_delta[i,i] uses Delta_i), minus itself
+        for (int s = 0; s <= K; ++s) list[s] = ~0ull;
+        // self entry: d_ii = min(-2 l_i, dhat_i), ratio 1 -> log 0, never a collision (:323-325)
+        const float dii = fminf(-li - li, dhat);
+        list[0] = nbr_key(dii, agent);
+        int in_range = ((dii <= delta_i) ? 1 : 0) - 1;        // :346 (N_delta[i,i] uses Delta_i), minus itself
 
-            for (int r0 = 1; r0 < N; r0 += 64) {
-                // ---- pass 1: far filter, 16 LDS reads in flight.  Result: one bit per partner to revisit.
+        // pass 2 body: the pair (this agent, partner at index jdup of the doubled position array)
+        auto visit = [&](int jdup) {
+            const float2 pj = spos_env[jdup];
+            const int j = jdup - ((jdup >= N) ? N : 0);
+            const float2 cj = sconst[j];                                      // (Delta_j, l_j)
+            const float dx = xi - pj.x, dy = yi - pj.y;
+            const float dist = __builtin_amdgcn_sqrtf(fmaf(dy, dy, dx * dx));
+            float d = fminf(dist - li - cj.y, dhat);                          // :318
+            d = (d == 0.0f) ? -1e-6f : d;                                     // :319-320
+            const bool coll = d < 0.0f;                                       // :327 (dhat > 0)
+            // log(dhat/d) = ln2 * (log2 dhat - log2 d); collisions contribute 9990 (:330-332)
+            const float lg = coll ? 9.99e3f : kLn2 * (log2_dhat - __builtin_amdgcn_logf(d));
+            const bool inm = d <= cj.x;                                       // :328 (Delta_j!)
+            s_all += lg;                                                      // :283
+            s_msk += inm ? lg : 0.0f;                                         // :282
+            ncoll += coll ? 1 : 0;                                            // :284
+            in_range += inm ? 1 : 0;
+            nbr_insert<K>(list, nbr_key(d, j));                               // :338
+        };
+
+        if (valid) {
+            // partners to scan "forward": all N-1 of them, or (symmetric variants) only the nearer half --
+            // the other end of each pair then gets the verdict through a ballot (kSym64) or an LDS bit (SYMB)
+            const int rmax = SYMB ? N / 2 : N - 1;
+            for (int r0 = 1; r0 <= rmax; r0 += 64) {
+                // ---- pass 1: far filter, 16 partners in flight.  Result: one bit per partner to revisit.
                 unsigned long long near = 0ull;
-                const int left = N - r0;
+                const int left = rmax - r0 + 1;
 #if defined(DRONESIM_ABLATE_PASS1)
                 if (true) { near = (xi == 123.456f) ? 1ull : 0ull; } else
 #endif
@@ -346,6 +374,17 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
                                 m |= (d2 < thr ? 1u : 0u) << u;
                             }
                             if (cnt < kChunk) m &= (1u << cnt) - 1u;
+                            if (SYMB && __builtin_amdgcn_ballot_w64(m != 0u)) {   // rare: tell the other end of each hit
+                                unsigned mm = m;
+                                while (mm) {
+                                    const int r = r0 + c4 * kChunk + __builtin_ctz(mm);
+                                    mm &= mm - 1u;
+                                    if (2 * r != N) {                        // r = N/2: the partner scans this pair itself
+                                        int j = agent + r; j -= (j >= N) ? N : 0;
+                                        atomicOr(&sback[j * nbw + ((r - 1) >> 5)], 1u << ((r - 1) & 31));
+                                    }
+                                }
+                            }
                             near |= (unsigned long long)m << (c4 * kChunk);
                         }
                     }
@@ -357,26 +396,26 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
                 while (near) {
                     const int u = __builtin_ctzll(near);
                     near &= near - 1ull;
-                    int j = SYM ? (u < 32 ? agent + 1 + u : agent + 95 - u) : agent + r0 + u;
-                    const float2 pj = spos_env[j];
-                    j -= (j >= N) ? N : 0;
-                    const float2 cj = sconst[j];                              // (Delta_j, l_j)
-                    const float dx = xi - pj.x, dy = yi - pj.y;
-                    const float dist = __builtin_amdgcn_sqrtf(fmaf(dy, dy, dx * dx));
-                    float d = fminf(dist - li - cj.y, dhat);                  // :318
-                    d = (d == 0.0f) ? -1e-6f : d;                             // :319-320
-                    const bool coll = d < 0.0f;                               // :327 (dhat > 0)
-                    // log(dhat/d) = ln2 * (log2 dhat - log2 d); collisions contribute 9990 (:330-332)
-                    const float lg = coll ? 9.99e3f : kLn2 * (log2_dhat - __builtin_amdgcn_logf(d));
-                    const bool inm = d <= cj.x;                               // :328 (Delta_j!)
-                    s_all += lg;                                              // :283
-                    s_msk += inm ? lg : 0.0f;                                 // :282
-                    ncoll += coll ? 1 : 0;                                    // :284
-                    in_range += inm ? 1 : 0;
-                    nbr_insert<K>(list, nbr_key(d, j));                       // :338
+                    visit(SYM ? (u < 32 ? agent + 1 + u : agent + 95 - u) : agent + r0 + u);
                 }
             }
-
+        }
+        if (SYMB) {
+            // ---- other half: partners that found THIS agent near while scanning forward left a bit in LDS
+            group_sync<WL>();
+            if (valid) {
+                for (int w = 0; w < nbw; ++w) {
+                    unsigned m = sback[agent * nbw + w];
+                    sback[agent * nbw + w] = 0u;                               // ready for the next step
+                    while (m) {
+                        const int u = __builtin_ctz(m);
+                        m &= m - 1u;
+                        visit(agent + N - (w * 32 + u + 1));                   // partner i - r
+                    }
+                }
+            }
+        }
+        if (valid) {
             TRACE_MARK(3);
             // rewards (:276, :287-288)
             const float gx = xFx - xi, gy = xFy - yi;
@@ -757,6 +796,7 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k)
     red += (red & 3) ? 4 - (red & 3) : 0;
     b += sizeof(int) * red;
     b += sizeof(unsigned) * nwaves * kWave * 3 * (size_t)(k + 1);   // z (2 words) + Ni (1 word) per lane
+    if (g.P == 0) b += sizeof(unsigned) * (size_t)N * ((N / 2 + 31) / 32);   // SYMB backward bits
     return b;
 }
 
