@@ -104,11 +104,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # BENCH_BACKEND=gloo BENCH_ONE_DEVICE=1 lets the launcher path (ranks, barrier, max-over-ranks, gather) be
+    # exercised with several ranks on a single GPU; the graded runs use RCCL with one GPU per rank
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     N, e_gpu, G, delta, label = WORKLOADS[args.workload]
     if args.envs_per_gpu:
@@ -144,6 +152,7 @@ def main():
             env.reset(renew_obstacles=False)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -210,7 +219,7 @@ def main():
     except RuntimeError:                               # e.g. not enough memory for the [T, ...] outputs
         ro_us = None
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     # the path's only exchange: all-gather of the global reward statistic (RCCL over xGMI when world > 1)

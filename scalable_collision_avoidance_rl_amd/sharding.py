@@ -42,9 +42,12 @@ def all_gather_stats(vec, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return vec.view(1, -1).clone()
     world = dist.get_world_size(group)
-    out = torch.empty(world, vec.numel(), dtype=vec.dtype, device=vec.device)
-    dist.all_gather_into_tensor(out, vec.view(1, -1).contiguous(), group=group)
-    return out
+    src = vec.view(1, -1).contiguous()
+    if dist.get_backend(group) == "gloo" and src.is_cuda:      # gloo gathers host tensors (CPU tests, debugging)
+        src = src.cpu()
+    out = torch.empty(world, vec.numel(), dtype=vec.dtype, device=src.device)
+    dist.all_gather_into_tensor(out, src, group=group)
+    return out.to(vec.device)
 
 
 def summarize(gathered):
