@@ -110,7 +110,9 @@ int dronesim_reset(const DroneParams *p, int div_x, int div_y, float pitch,
  * SAC_agents.py:9-22).  act is [T][E][N][2]; every per-step output of
  * dronesim_step is written for every step into [T][...] buffers laid out as T
  * consecutive copies of the per-step layout; pos/vel/t hold the final state.
- * Envs are NOT reset inside the rollout (t keeps counting, done stays set).       */
+ * Envs are NOT reset inside the rollout (t keeps counting, done stays set).
+ * For N = 64 the far filter's verdicts (taken with radius reach + skin, skin = 0.4 reach) are kept in
+ * registers and reused until some agent of the env has moved more than skin/2: bit-identical results. */
 int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
                      float *reward, float *true_reward, float *z, int32_t *nbr_idx,
                      int32_t *n_coll, uint8_t *done, int E, int T, void *stream);

@@ -67,6 +67,7 @@ struct KArgs {
     int *nbr_idx, *n_coll;
     uint8_t *done;
     const uint8_t *mask;
+    float skin;                     // rollout, kSym64: slack radius of the register-resident candidate list
 };
 
 // (d, j) as ONE unsigned key whose integer order is the lexicographic order of the pair:
@@ -140,6 +141,8 @@ enum Geo { kPacked = 0, kSym64 = 1, kBlock256 = 2, kBlock1024 = 3 };
 
 template <int GEO> struct GeoTraits {
     static constexpr int kMaxThreads = GEO == kBlock1024 ? 1024 : 256;
+    // C3 needs 4 resident waves per SIMD (4096 envs = 4096 waves on 1024 SIMDs): cap the register budget at 128
+    static constexpr int kMinWavesPerSimd = GEO == kBlock1024 ? 1 : 4;
     static constexpr bool kWaveLocal = GEO == kPacked || GEO == kSym64;
 };
 
@@ -156,7 +159,7 @@ __device__ __forceinline__ void group_sync()
 }
 
 template <int K, bool FAR, int MODE, int GEO>
-__global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(const KArgs a)
+__global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::kMinWavesPerSimd) drone_kernel(const KArgs a)
 {
     constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
     constexpr bool SYM = GEO == kSym64;
@@ -259,6 +262,17 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
     const int nsteps = (MODE == kRollout) ? a.T : 1;
     const bool staged = a.c == 2 && !masked;                 // z / Ni leave through LDS as full lines
 
+    // ---- candidate list (fused rollout of kSym64 only): the far filter is run with radius reach + skin and
+    // its verdicts are kept in registers until some agent of the env has moved more than skin/2 from where
+    // they were taken -- by the triangle inequality every pair inside `reach` is then still on the list.
+    // Outputs are bit-identical to filtering every step: listed pairs beyond `reach` are skipped by the
+    // exact test in pass 2.
+    constexpr bool CACHED = SYM && MODE == kRollout;
+    const float thr_list = CACHED ? (reach + a.skin) * (reach + a.skin) * 1.000001f : thr;
+    const float moved2 = 0.49f * a.skin * 0.49f * a.skin;
+    unsigned long long cand = 0ull;
+    float refx = __builtin_nanf(""), refy = refx;            // NaN = no list yet
+
     for (int step = 0; step < nsteps; ++step) {
         const size_t so = (MODE == kRollout) ? (size_t)step * step_agents : 0;   // output offset (agents)
         const float *velsrc = (MODE == kObserve) ? a.vel : a.act + 2 * so;       // v of other agents
@@ -298,7 +312,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
             const int j = jdup - ((jdup >= N) ? N : 0);
             const float2 cj = sconst[j];                                      // (Delta_j, l_j)
             const float dx = xi - pj.x, dy = yi - pj.y;
-            const float dist = __builtin_amdgcn_sqrtf(fmaf(dy, dy, dx * dx));
+            const float d2 = fmaf(dy, dy, dx * dx);
+            if (CACHED && !(d2 < thr)) return;                                // listed but currently far
+            const float dist = __builtin_amdgcn_sqrtf(d2);
             float d = fminf(dist - li - cj.y, dhat);                          // :318
             d = (d == 0.0f) ? -1e-6f : d;                                     // :319-320
             const bool coll = d < 0.0f;                                       // :327 (dhat > 0)
@@ -327,6 +343,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
                     near = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
                 } else if (SYM) {
                     // bit u < 32: partner i+1+u ("forward");  bit 32+u: partner i-1-u ("backward", u < 31)
+                    bool rebuild = true;
+                    if (CACHED) {
+                        const float mx = xi - refx, my = yi - refy;
+                        rebuild = __builtin_amdgcn_ballot_w64(!(fmaf(my, my, mx * mx) <= moved2)) != 0ull;
+                        near = cand;
+                    }
+                    if (rebuild) {
                     unsigned mf = 0u, mb = 0u;
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
@@ -342,7 +365,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
                             const int r = 1 + c2 * kChunk + u;                // 1..32
                             const float dx = xi - pj[u].x, dy = yi - pj[u].y;
                             const float d2 = fmaf(dy, dy, dx * dx);
-                            const bool f = d2 < thr;
+                            const bool f = d2 < thr_list;
                             const unsigned long long fm = __builtin_amdgcn_ballot_w64(f);
                             if (fm) {                                         // wave-uniform: ~2/3 of the offsets have no hit
                                 mf |= (f ? 1u : 0u) << (r - 1);
@@ -354,6 +377,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads) drone_kernel(cons
                         }
                     }
                     near = (unsigned long long)mf | ((unsigned long long)mb << 32);
+                    if (CACHED) { cand = near; refx = xi; refy = yi; }
+                    }
                 } else {
 #pragma unroll
                     for (int c4 = 0; c4 < 4; ++c4) {
@@ -927,6 +952,7 @@ int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, c
     KArgs a{};
     a.pos = pos; a.vel = vel; a.t = t; a.act = act; a.reward = reward; a.true_reward = true_reward;
     a.z = z; a.nbr_idx = nbr_idx; a.n_coll = n_coll; a.done = done; a.T = T;
+    a.skin = 0.4f * (p->d_hat_max + 2.0f * p->radius_max);
     return launch(kRollout, p, a, E, stream);
 }
 

@@ -679,3 +679,25 @@ def test_invariances(torch):
 def formation_xF(N, G):
     from scalable_collision_avoidance_rl_amd import formation_O
     return formation_O(N, [G, G])[0].reshape(N, 2).astype(np.float32)
+
+
+def test_rollout_candidate_list_is_bit_transparent(torch):
+    """The fused rollout of N = 64 keeps the far filter's verdicts in registers between steps (list radius
+    reach + skin, refreshed once an agent has moved skin/2); the per-launch step kernel filters every step.
+    Both must agree bit for bit over long trajectories with slow, fast and very fast agents."""
+    N, G, E, T = 64, 28.0, 256, 150
+    a = make_env(N, G, 2, 2, np.ones(N), E, seed=77)
+    b = make_env(N, G, 2, 2, np.ones(N), E, seed=77)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    act = torch.rand(T, E, N, 2, device="cuda:0", generator=g) * 2 - 1
+    act[::7] *= 4.0                                            # bursts: several list refreshes in a row
+    act[50:60, ::4] = 0.0                                      # and envs that do not move at all
+    act[100] *= 40.0                                           # teleport-sized jump
+    out = a.rollout(act)
+    for s in range(T):
+        res = b.step(act[s])
+        for name, ref in (("reward", res.rewards), ("true_reward", res.true_rewards), ("z", res.z_states),
+                          ("nbr_idx", b.nbr_idx), ("n_coll", res.n_collisions), ("done", res.finished)):
+            assert torch.equal(out[name][s], ref), (name, s)
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.t, b.t)
+    assert int(out["n_coll"].sum()) > 0
