@@ -585,8 +585,7 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N;
-    int *snode = reinterpret_cast<int *>(smem);            // [epb][N] settled node or -1
-    int *scand = snode + (size_t)a.epb * N;                // [epb][N] proposal of this round or -1
+    int2 *sst = reinterpret_cast<int2 *>(smem);            // [epb][N] (settled node or -1, proposal of this round or -1)
     const int tid = threadIdx.x;
     int slot, agent;
     bool valid;
@@ -604,7 +603,7 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
     if (valid && a.mask != nullptr) valid = a.mask[env] != 0;
     const uint32_t gid = (uint32_t)(a.env_base + env);
     const uint32_t epi = valid ? (uint32_t)a.episode[env] : 0u;   // resets this env has seen so far
-    int *mynode = snode + (size_t)slot * N, *mycand = scand + (size_t)slot * N;
+    int2 *mine = sst + (size_t)slot * N;
 
     int node = -1;
     int remaining;
@@ -616,19 +615,19 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
                 const uint32_t w = philox4x32_10_word0((uint32_t)agent, round, gid, epi, a.key0, a.key1);
                 cand = (int)__umulhi(w, a.M);
             }
-            mynode[agent] = node;
-            mycand[agent] = cand;
+            mine[agent] = make_int2(node, cand);
         }
         __syncthreads();
         if (valid && node < 0) {
-            bool ok = true;
+            bool clash = false;                                       // branch-free so the LDS reads pipeline
+#pragma unroll 8
             for (int j = 0; j < N; ++j) {
-                if (j == agent) continue;
-                const int nj = mynode[j];
-                if (nj >= 0) ok = ok && (nj != cand);                 // held since an earlier round
-                else if (j < agent) ok = ok && (mycand[j] != cand);   // lower index wins the round
+                const int2 o = mine[j];
+                const bool held = o.x >= 0 && o.x == cand;            // held since an earlier round
+                const bool lower = o.x < 0 && j < agent && o.y == cand;   // lower index wins the round
+                clash = clash || held || lower;
             }
-            if (ok) node = cand;
+            if (!clash) node = cand;
         }
         remaining = __syncthreads_count(valid && node < 0);
         ++round;
