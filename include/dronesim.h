@@ -167,6 +167,21 @@ int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *a
                          uint64_t seed, uint64_t counter, int64_t env_base,
                          const int32_t *t, const int32_t *episode, int E, void *stream);
 
+/* Opt-in bfloat16 variant of dronesim_mlp_forward (weights and activations in bf16, float32 accumulation,
+ * ~16x the matrix rate; outputs agree with the float32 path to bf16 round-off, ~1e-2 relative).
+ * Weights are pre-packed per matrix-core fragment: for a layer with K inputs and F outputs,
+ *   wp[agent][c][s][lane][j] = W[16 s + 8 (lane >> 5) + j][32 c + (lane & 31)]   (0 beyond K or F)
+ * for feature chunks c < ceil(F/32), k-steps s and j < 8, as bf16 (16 bytes per lane).  k-steps:
+ * layer 1: 1 (d_in <= 16), layer 2: 2 ceil(h1/32), layer 3: 2 ceil(h2/32) with a single chunk (nout <= 32).  */
+typedef struct DroneMlpBf16 {
+    int32_t N, d_in, h1, h2, nout, out_kind, sample_kind, reserved;
+    const void *w1p, *w2p, *w3p;     /* packed bf16 fragments */
+    const float *b1, *b2, *b3;       /* [N][h1], [N][h2], [N][nout] float32 */
+} DroneMlpBf16;
+int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                              uint64_t seed, uint64_t counter, int64_t env_base,
+                              const int32_t *t, const int32_t *episode, int E, void *stream);
+
 const char *dronesim_last_error(void);
 const char *dronesim_error_string(int code);
 int dronesim_version(void);

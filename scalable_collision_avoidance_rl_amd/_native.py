@@ -21,7 +21,7 @@ MAX_K = 8
 MAX_AGENTS = 1024
 
 # every symbol include/dronesim.h declares (tests check the .so exports all of them)
-SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_mlp_forward",
+SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -41,6 +41,14 @@ class DroneMlp(C.Structure):
                 ("out_kind", C.c_int32), ("sample_kind", C.c_int32), ("reserved", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
                 ("w3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class DroneMlpBf16(C.Structure):
+    """Mirror of `struct DroneMlpBf16` (include/dronesim.h)."""
+    _fields_ = [("N", C.c_int32), ("d_in", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("nout", C.c_int32),
+                ("out_kind", C.c_int32), ("sample_kind", C.c_int32), ("reserved", C.c_int32),
+                ("w1p", C.c_void_p), ("w2p", C.c_void_p), ("w3p", C.c_void_p),
+                ("b1", C.c_void_p), ("b2", C.c_void_p), ("b3", C.c_void_p)]
 
 
 class DroneSimError(RuntimeError):
@@ -76,6 +84,8 @@ def lib():
     L.dronesim_returns.restype = L.dronesim_advantage.restype = C.c_int
     L.dronesim_mlp_forward.argtypes = [C.POINTER(DroneMlp), vp, vp, vp, vp, u64, u64, i64, vp, vp, i32, vp]
     L.dronesim_mlp_forward.restype = C.c_int
+    L.dronesim_mlp_forward_bf16.argtypes = [C.POINTER(DroneMlpBf16), vp, vp, vp, vp, u64, u64, i64, vp, vp, i32, vp]
+    L.dronesim_mlp_forward_bf16.restype = C.c_int
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
     for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset",
                  "dronesim_version"):

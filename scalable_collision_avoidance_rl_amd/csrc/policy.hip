@@ -33,18 +33,84 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kRows = 64;            // env rows per workgroup
 constexpr int kMaxOut = 32;
 
-struct MArgs {
-    int E, N, d_in, h1, h2, nout, out_kind, sample_kind;
-    const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
+struct FinishArgs {
+    int N, nout, out_kind, sample_kind;
     float *out, *act;
     int *act_idx;
     uint32_t key0, key1, ctr2, ctr3;
     long long env_base;
-    const int *t_dev, *episode_dev;      // optional per-env stream ids kept on the device (graph-replay safe)
+    const int *t_dev, *episode_dev;
+};
+
+struct MArgs {
+    int E, N, d_in, h1, h2, nout;
+    const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
+    FinishArgs fin;
 };
 
 // C/D layout of v_mfma_f32_32x32x2_f32: element reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31)
 __device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Output activation + sampling of ONE env row (y = pre-activation outputs of this row's agent network).
+
+__device__ __forceinline__ void finish_row(const FinishArgs &a, float (&y)[kMaxOut], int e, int agent)
+{
+    const int nout = a.nout;
+    if (a.out_kind == 1) {                                   // softmax (utils.py:286, dim = 0 of one sample)
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int j = 0; j < kMaxOut; ++j) if (j < nout) m = fmaxf(m, y[j]);
+        float ssum = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kMaxOut; ++j) { y[j] = j < nout ? expf(y[j] - m) : 0.0f; ssum += y[j]; }
+        const float inv = 1.0f / ssum;
+#pragma unroll
+        for (int j = 0; j < kMaxOut; ++j) y[j] *= inv;
+    } else if (a.out_kind == 2) {                            // tanh means, sigmoid variances (utils.py:74-77)
+        const int half = nout / 2;
+#pragma unroll
+        for (int j = 0; j < kMaxOut; ++j)
+            if (j < nout) y[j] = j < half ? tanhf(y[j]) : 1.0f / (1.0f + expf(-y[j]));
+    }
+    const size_t row = (size_t)e * a.N + agent;
+    if (a.out) {
+#pragma unroll
+        for (int j = 0; j < kMaxOut; ++j) if (j < nout) a.out[row * nout + j] = y[j];
+    }
+    if (a.sample_kind != 0) {
+        uint32_t rnd[4];
+        const uint32_t c2 = a.ctr2 + (a.t_dev ? (uint32_t)a.t_dev[e] : 0u);
+        const uint32_t c3 = a.ctr3 + (a.episode_dev ? (uint32_t)a.episode_dev[e] : 0u);
+        philox4x32_10((uint32_t)agent, (uint32_t)(a.env_base + e), c2, c3, a.key0, a.key1, rnd);
+        if (a.sample_kind == 1) {                            // categorical -> unit vector (utils.py:262-269, 304-309)
+            const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
+            float cdf = 0.0f;
+            int pick = nout - 1;
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < kMaxOut; ++j) {
+                if (j < nout) {
+                    cdf += y[j];
+                    if (!found && u < cdf) { pick = j; found = true; }
+                }
+            }
+            if (a.act_idx) a.act_idx[row] = pick;
+            if (a.act) {
+                const float ang = (float)pick / (float)nout * 6.283185307179586f;
+                a.act[row * 2 + 0] = cosf(ang);
+                a.act[row * 2 + 1] = sinf(ang);
+            }
+        } else {                                             // Gaussian, Box-Muller (utils.py:110-117)
+            const int half = nout / 2;
+            for (int d = 0; d < half && d < 2; ++d) {
+                const float u1 = ((float)(rnd[2 * d] >> 8) + 1.0f) * (1.0f / 16777216.0f);    // (0, 1]
+                const float u2 = (float)(rnd[2 * d + 1] >> 8) * (1.0f / 16777216.0f);
+                const float n01 = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+                if (a.act) a.act[row * half + d] = fmaf(sqrtf(y[half + d]), n01, y[d]);
+            }
+        }
+    }
+}
 
 // (acc0, acc1) += A[64 x K] * B[K x 32] for the two 32-row halves of A, sharing every B fragment.
 // A row-major in LDS (lda floats per row, odd stride -> conflict-free), B row-major in global / L2 (ldb
@@ -184,89 +250,227 @@ __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
             }
             y[j] = v;
         }
-        if (a.out_kind == 1) {                                   // softmax (utils.py:286, dim = 0 of one sample)
-            float m = -__builtin_inff();
+        finish_row(a.fin, y, e, agent);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16 variant (opt-in): weights and activations in bfloat16, float32 accumulation, on
+// v_mfma_f32_32x32x16_bf16 (16x the float32 matrix rate).  Formulated transposed -- D[feature][env row] =
+// W^T (A operand, pre-packed per fragment on the host, one 16-byte load per lane) x activations (B operand,
+// LDS, [row][k] row-major, one ds_read_b128 per lane) -- so that a lane's 4 consecutive accumulator
+// registers are 4 consecutive features of ONE env row and leave as one packed 8-byte LDS store.
+// One workgroup = 128 env rows of one agent (4 row tiles share every weight fragment), 4 waves, wave w owns
+// feature chunks w, w+4, ...  LDS row strides are odd multiples of 16 bytes (conflict-free b128 reads).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kRowsB = 128, kTiles = 4;
+constexpr int kLdx = 24, kLds = 40;      // bf16 per row of the x tile / of a staged 32-feature chunk
+
+struct MArgsB {
+    int E, N, d_in, h1, h2, nc1, nc2, ks1;
+    const float *x, *b1, *b2, *b3;
+    const bf16x8 *w1p, *w2p, *w3p;       // [agent][chunk][k-step][64 lanes] fragments
+    FinishArgs fin;
+};
+
+// acc[t] += W^T chunk (k-steps [0, ks)) x activation rows of tile t
+__device__ __forceinline__ void chunk_gemm(f32x16 (&acc)[kTiles], const bf16x8 *__restrict__ wfrag, int ks,
+                                           const __bf16 *act, int ld, int lane)
+{
+    const __bf16 *brow = act + (lane & 31) * ld + 8 * (lane >> 5);
+    int s = 0;
+    for (; s + 2 <= ks; s += 2) {                          // two k-steps in flight
+        const bf16x8 a0 = wfrag[(size_t)s * 64 + lane], a1 = wfrag[(size_t)(s + 1) * 64 + lane];
+        bf16x8 b0[kTiles], b1[kTiles];
 #pragma unroll
-            for (int j = 0; j < kMaxOut; ++j) if (j < nout) m = fmaxf(m, y[j]);
-            float ssum = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kMaxOut; ++j) { y[j] = j < nout ? expf(y[j] - m) : 0.0f; ssum += y[j]; }
-            const float inv = 1.0f / ssum;
-#pragma unroll
-            for (int j = 0; j < kMaxOut; ++j) y[j] *= inv;
-        } else if (a.out_kind == 2) {                            // tanh means, sigmoid variances (utils.py:74-77)
-            const int half = nout / 2;
-#pragma unroll
-            for (int j = 0; j < kMaxOut; ++j)
-                if (j < nout) y[j] = j < half ? tanhf(y[j]) : 1.0f / (1.0f + expf(-y[j]));
+        for (int t = 0; t < kTiles; ++t) {
+            b0[t] = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + s * 16);
+            b1[t] = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + s * 16 + 16);
         }
-        const size_t row = (size_t)e * a.N + agent;
-        if (a.out) {
 #pragma unroll
-            for (int j = 0; j < kMaxOut; ++j) if (j < nout) a.out[row * nout + j] = y[j];
-        }
-        if (a.sample_kind != 0) {
-            uint32_t rnd[4];
-            const uint32_t c2 = a.ctr2 + (a.t_dev ? (uint32_t)a.t_dev[e] : 0u);
-            const uint32_t c3 = a.ctr3 + (a.episode_dev ? (uint32_t)a.episode_dev[e] : 0u);
-            philox4x32_10((uint32_t)agent, (uint32_t)(a.env_base + e), c2, c3, a.key0, a.key1, rnd);
-            if (a.sample_kind == 1) {                            // categorical -> unit vector (utils.py:262-269, 304-309)
-                const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
-                float cdf = 0.0f;
-                int pick = nout - 1;
-                bool found = false;
+        for (int t = 0; t < kTiles; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[t], acc[t], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < kMaxOut; ++j) {
-                    if (j < nout) {
-                        cdf += y[j];
-                        if (!found && u < cdf) { pick = j; found = true; }
-                    }
-                }
-                if (a.act_idx) a.act_idx[row] = pick;
-                if (a.act) {
-                    const float ang = (float)pick / (float)nout * 6.283185307179586f;
-                    a.act[row * 2 + 0] = cosf(ang);
-                    a.act[row * 2 + 1] = sinf(ang);
-                }
-            } else {                                             // Gaussian, Box-Muller (utils.py:110-117)
-                const int half = nout / 2;
-                for (int d = 0; d < half && d < 2; ++d) {
-                    const float u1 = ((float)(rnd[2 * d] >> 8) + 1.0f) * (1.0f / 16777216.0f);    // (0, 1]
-                    const float u2 = (float)(rnd[2 * d + 1] >> 8) * (1.0f / 16777216.0f);
-                    const float n01 = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-                    if (a.act) a.act[row * half + d] = fmaf(sqrtf(y[half + d]), n01, y[d]);
-                }
-            }
+        for (int t = 0; t < kTiles; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[t], acc[t], 0, 0, 0);
+    }
+    for (; s < ks; ++s) {
+        const bf16x8 a0 = wfrag[(size_t)s * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + s * 16);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[t], 0, 0, 0);
         }
     }
 }
 
+// relu(acc + bias) of one 32-feature chunk -> bf16 rows [row][feature] (features >= nvalid are written as 0)
+__device__ __forceinline__ void store_chunk(const f32x16 (&acc)[kTiles], const float *__restrict__ bias, int f0, int nvalid,
+                                            __bf16 *dst, int ld, int lane)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int fl = 8 * q + 4 * (lane >> 5);            // local feature of register 4q (C/D layout rows)
+        float bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = (f0 + fl + i) < nvalid ? bias[f0 + fl + i] : 0.0f;
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+            bf16x4 p;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                p[i] = (__bf16)((f0 + fl + i) < nvalid ? fmaxf(acc[t][4 * q + i] + bv[i], 0.0f) : 0.0f);
+            *reinterpret_cast<bf16x4 *>(dst + (t * 32 + (lane & 31)) * ld + fl) = p;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) mlp3_bf16_kernel(const MArgsB a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int agent = blockIdx.y;
+    const int e0 = blockIdx.x * kRowsB;
+    const int ld1 = a.nc1 * 32 + 8;
+    __bf16 *sx = reinterpret_cast<__bf16 *>(smem);                 // [128][24]
+    __bf16 *sst = sx + kRowsB * kLdx;                              // [4 waves][128][40]
+    __bf16 *sh1 = sst + 4 * kRowsB * kLds;                         // [128][ld1]; later the f32 partials [4][128][33]
+    float *spart = reinterpret_cast<float *>(sh1);
+
+    for (int idx = tid; idx < kRowsB * 16; idx += 256) {           // x tile, zero padded to k = 16
+        const int r = idx >> 4, c = idx & 15;
+        const int e = e0 + r;
+        const float v = (c < a.d_in && e < a.E) ? a.x[((size_t)e * a.N + agent) * a.d_in + c] : 0.0f;
+        sx[r * kLdx + c] = (__bf16)v;
+    }
+    __syncthreads();
+
+    // ---- layer 1 -> sh1 (bf16)
+    for (int c = wave; c < a.nc1; c += 4) {
+        f32x16 acc[kTiles] = {};
+        chunk_gemm(acc, a.w1p + ((size_t)agent * a.nc1 + c) * a.ks1 * 64, a.ks1, sx, kLdx, lane);
+        store_chunk(acc, a.b1 + (size_t)agent * a.h1, c * 32, a.h1, sh1 + c * 32, ld1, lane);
+    }
+    __syncthreads();
+
+    // ---- layers 2 + 3 fused over this wave's feature chunks
+    f32x16 y[kTiles] = {};
+    __bf16 *st = sst + wave * kRowsB * kLds;
+    const int ks2 = a.nc1 * 2;
+    for (int c = wave; c < a.nc2; c += 4) {
+        f32x16 acc[kTiles] = {};
+        chunk_gemm(acc, a.w2p + ((size_t)agent * a.nc2 + c) * ks2 * 64, ks2, sh1, ld1, lane);
+        store_chunk(acc, a.b2 + (size_t)agent * a.h2, c * 32, a.h2, st, kLds, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        chunk_gemm(y, a.w3p + ((size_t)agent * a.nc2 * 2 + 2 * c) * 64, 2, st, kLds, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();                                               // everyone is done reading sh1
+#pragma unroll
+    for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            spart[((size_t)wave * kRowsB + t * 32 + (lane & 31)) * 33 + cd_row(r, lane)] = y[t][r];
+    __syncthreads();
+
+    if (tid < kRowsB) {
+        const int e = e0 + tid;
+        if (e >= a.E) return;
+        const float *b3 = a.b3 + (size_t)agent * a.fin.nout;
+        float yv[kMaxOut];
+#pragma unroll
+        for (int j = 0; j < kMaxOut; ++j) {
+            float v = 0.0f;
+            if (j < a.fin.nout) {
+                v = b3[j];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += spart[((size_t)w * kRowsB + tid) * 33 + j];
+            }
+            yv[j] = v;
+        }
+        finish_row(a.fin, yv, e, agent);
+    }
+}
+
+FinishArgs make_finish(int N, int nout, int out_kind, int sample_kind, float *out, float *act, int32_t *act_idx,
+                       uint64_t seed, uint64_t counter, int64_t env_base, const int32_t *t, const int32_t *episode)
+{
+    FinishArgs f{};
+    f.N = N; f.nout = nout; f.out_kind = out_kind; f.sample_kind = sample_kind;
+    f.out = out; f.act = act; f.act_idx = act_idx;
+    f.key0 = (uint32_t)seed; f.key1 = (uint32_t)(seed >> 32);
+    f.ctr2 = (uint32_t)counter; f.ctr3 = (uint32_t)(counter >> 32);
+    f.env_base = env_base; f.t_dev = t; f.episode_dev = episode;
+    return f;
+}
+
+int check_mlp(const char *who, int N, int d_in, int h1, int h2, int nout, int out_kind, int sample_kind, int E)
+{
+    (void)who;
+    if (N < 1 || d_in < 1 || d_in > 64 || h1 < 1 || h1 > 512 || h2 < 1 || h2 > 512 || nout < 1 || nout > kMaxOut)
+        return dronesim_fail(DRONESIM_EUNSUPPORTED, "mlp forward: need d_in<=64, h1,h2<=512, nout<=32");
+    if (out_kind < 0 || out_kind > 2 || sample_kind < 0 || sample_kind > 2)
+        return dronesim_fail(DRONESIM_EINVAL, "mlp forward: bad out_kind / sample_kind");
+    if (sample_kind == 2 && (out_kind != 2 || nout != 4))
+        return dronesim_fail(DRONESIM_EINVAL, "Gaussian sampling needs out_kind 2 with nout = 4 (mu_x, mu_y, var_x, var_y)");
+    if (E < 0) return dronesim_fail(DRONESIM_EINVAL, "E < 0");
+    return DRONESIM_OK;
+}
+
 }   // namespace
+
+extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                                         uint64_t seed, uint64_t counter, int64_t env_base,
+                                         const int32_t *t, const int32_t *episode, int E, void *stream)
+{
+    if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16: NULL argument");
+    const int rc = check_mlp("bf16", m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
+    if (rc) return rc;
+    if (m->d_in > 16) return dronesim_fail(DRONESIM_EUNSUPPORTED, "bf16 path: d_in <= 16");
+    if (!m->w1p || !m->w2p || !m->w3p || !m->b1 || !m->b2 || !m->b3)
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16: NULL weight array");
+    if (E == 0) return DRONESIM_OK;
+    MArgsB a{};
+    a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2;
+    a.nc1 = (m->h1 + 31) / 32; a.nc2 = (m->h2 + 31) / 32; a.ks1 = 1;
+    a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
+    a.w1p = reinterpret_cast<const bf16x8 *>(m->w1p); a.w2p = reinterpret_cast<const bf16x8 *>(m->w2p);
+    a.w3p = reinterpret_cast<const bf16x8 *>(m->w3p);
+    a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
+    const size_t sh1_bytes = sizeof(__bf16) * kRowsB * ((size_t)a.nc1 * 32 + 8);
+    const size_t part_bytes = sizeof(float) * 4 * kRowsB * 33;
+    const size_t lds = sizeof(__bf16) * (kRowsB * kLdx + 4 * kRowsB * kLds) + (sh1_bytes > part_bytes ? sh1_bytes : part_bytes);
+    static bool big_lds_enabled = false;
+    if (!big_lds_enabled) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return dronesim_fail(DRONESIM_ELAUNCH, "cannot enable 160 KiB of dynamic LDS for mlp3_bf16_kernel");
+        big_lds_enabled = true;
+    }
+    if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
+    hipLaunchKernelGGL(mlp3_bf16_kernel, dim3((E + kRowsB - 1) / kRowsB, m->N), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
+}
 
 extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,
                                     uint64_t seed, uint64_t counter, int64_t env_base,
                                     const int32_t *t, const int32_t *episode, int E, void *stream)
 {
     if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL argument");
-    if (m->N < 1 || m->d_in < 1 || m->d_in > 64 || m->h1 < 1 || m->h1 > 512 || m->h2 < 1 || m->h2 > 512 ||
-        m->nout < 1 || m->nout > kMaxOut)
-        return dronesim_fail(DRONESIM_EUNSUPPORTED, "dronesim_mlp_forward: need d_in<=64, h1,h2<=512, nout<=32");
+    const int rc = check_mlp("f32", m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
+    if (rc) return rc;
     if (!m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3)
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
-    if (m->out_kind < 0 || m->out_kind > 2 || m->sample_kind < 0 || m->sample_kind > 2)
-        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: bad out_kind / sample_kind");
-    if (m->sample_kind == 2 && (m->out_kind != 2 || m->nout != 4))
-        return dronesim_fail(DRONESIM_EINVAL, "Gaussian sampling needs out_kind 2 with nout = 4 (mu_x, mu_y, var_x, var_y)");
-    if (E < 0) return dronesim_fail(DRONESIM_EINVAL, "E < 0");
     if (E == 0) return DRONESIM_OK;
     MArgs a{};
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2; a.nout = m->nout;
-    a.out_kind = m->out_kind; a.sample_kind = m->sample_kind;
     a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
-    a.out = out; a.act = act; a.act_idx = act_idx;
-    a.key0 = (uint32_t)seed; a.key1 = (uint32_t)(seed >> 32);
-    a.ctr2 = (uint32_t)counter; a.ctr3 = (uint32_t)(counter >> 32);
-    a.env_base = env_base; a.t_dev = t; a.episode_dev = episode;
+    a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
     const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + 4 * 64 * 33);
     static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
     if (!big_lds_enabled) {

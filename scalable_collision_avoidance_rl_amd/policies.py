@@ -26,9 +26,23 @@ def _wt(layer):
     return layer.weight.detach().t().contiguous().float(), layer.bias.detach().contiguous().float()
 
 
+def pack_bf16_fragments(w, ksteps, nchunks):
+    """[N, K, F] float weights -> matrix-core fragments [N, nchunks, ksteps, 64, 8] in bf16
+    (frag[a, c, s, l, j] = w[a, 16 s + 8 (l >> 5) + j, 32 c + (l & 31)], zero beyond K / F) --
+    the layout `dronesim_mlp_forward_bf16` reads with one 16-byte load per lane."""
+    import torch
+    n, k, f = w.shape
+    pad = torch.zeros(n, ksteps * 16, nchunks * 32, dtype=torch.float32, device=w.device)
+    pad[:, :k, :f] = w
+    frag = pad.view(n, ksteps, 2, 8, nchunks, 32).permute(0, 4, 1, 2, 5, 3)      # [N, c, s, h, i, j]
+    return frag.reshape(n, nchunks, ksteps, 64, 8).to(torch.bfloat16).contiguous()
+
+
 class BatchedMLP:
-    def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0):
-        """w1 [N,d_in,h1], b1 [N,h1], w2 [N,h1,h2], b2 [N,h2], w3 [N,h2,nout], b3 [N,nout] (float32)."""
+    def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0, precision="f32"):
+        """w1 [N,d_in,h1], b1 [N,h1], w2 [N,h1,h2], b2 [N,h2], w3 [N,h2,nout], b3 [N,nout] (float32).
+        ``precision="f32"`` (default) is exact float32 on the matrix cores; ``"bf16"`` runs weights and
+        activations in bfloat16 with float32 accumulation (~1e-2 relative agreement, much faster)."""
         import torch
         from . import _native
         self._torch, self._native = torch, _native
@@ -49,6 +63,22 @@ class BatchedMLP:
         m.w1, m.b1, m.w2 = self.w1.data_ptr(), self.b1.data_ptr(), self.w2.data_ptr()
         m.b2, m.w3, m.b3 = self.b2.data_ptr(), self.w3.data_ptr(), self.b3.data_ptr()
         self._m = m
+        self.precision = precision
+        if precision == "bf16":
+            if self.d_in > 16:
+                raise ValueError("the bf16 path supports d_in <= 16")
+            nc1, nc2 = (self.h1 + 31) // 32, (self.h2 + 31) // 32
+            self._w1p = pack_bf16_fragments(self.w1, 1, nc1)
+            self._w2p = pack_bf16_fragments(self.w2, 2 * nc1, nc2)
+            self._w3p = pack_bf16_fragments(self.w3, 2 * nc2, 1)
+            mb = _native.DroneMlpBf16()
+            mb.N, mb.d_in, mb.h1, mb.h2, mb.nout = self.n_agents, self.d_in, self.h1, self.h2, self.nout
+            mb.out_kind, mb.sample_kind = self.out_kind, self.sample_kind
+            mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), self._w2p.data_ptr(), self._w3p.data_ptr()
+            mb.b1, mb.b2, mb.b3 = self.b1.data_ptr(), self.b2.data_ptr(), self.b3.data_ptr()
+            self._m = mb
+        elif precision != "f32":
+            raise ValueError("precision must be 'f32' or 'bf16'")
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -101,8 +131,9 @@ class BatchedMLP:
             act = torch.empty(E, self.n_agents, 2, device=self.device)
             if self.sample_kind == SAMPLE_CATEGORICAL:
                 idx = torch.empty(E, self.n_agents, dtype=torch.int32, device=self.device)
+        entry = self._lib.dronesim_mlp_forward_bf16 if self.precision == "bf16" else self._lib.dronesim_mlp_forward
         with torch.cuda.device(self.device):
-            rc = self._lib.dronesim_mlp_forward(C.byref(m), z.data_ptr(), None if out is None else out.data_ptr(),
+            rc = entry(C.byref(m), z.data_ptr(), None if out is None else out.data_ptr(),
                                                 None if act is None else act.data_ptr(),
                                                 None if idx is None else idx.data_ptr(), self.seed, self.counter,
                                                 int(env_base), None if env is None else env.t.data_ptr(),

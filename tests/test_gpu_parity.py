@@ -701,3 +701,36 @@ def test_rollout_candidate_list_is_bit_transparent(torch):
             assert torch.equal(out[name][s], ref), (name, s)
     assert torch.equal(a.pos, b.pos) and torch.equal(a.t, b.t)
     assert int(out["n_coll"].sum()) > 0
+
+
+def test_batched_policy_bf16_variant(torch):
+    """Opt-in bf16 path (dronesim_mlp_forward_bf16): against a torch emulation of its arithmetic (weights and
+    layer inputs rounded to bf16, float32 accumulation) it agrees tightly; against the exact float32 path
+    it agrees to bf16 round-off.  Shapes of all three reference networks, ragged E."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    g = torch.Generator().manual_seed(12)
+    N, E, d = 3, 333, 6
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float64)
+
+    def emul(x, w, act):
+        w1, b1, w2, b2, w3, b3 = w
+        h = torch.relu(torch.einsum("end,ndh->enh", bf(x), bf(w1)) + b1.double())
+        h = torch.relu(torch.einsum("enh,nhk->enk", bf(h.float()), bf(w2)) + b2.double())
+        y = torch.einsum("enk,nko->eno", bf(h.float()), bf(w3)) + b3.double()
+        return act(y).numpy()
+
+    x = torch.rand(E, N, d, generator=g) * 4 - 2
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1)
+    for (h1, h2, nout, ok, sk, act) in [
+            (300, 300, 16, 1, 1, lambda y: torch.softmax(y, -1)),
+            (400, 400, 4, 2, 2, lambda y: torch.cat([torch.tanh(y[..., :2]), torch.sigmoid(y[..., 2:])], -1)),
+            (200, 200, 1, 0, 0, lambda y: y)]:
+        w = (r(N, d, h1) * 0.4, r(N, h1) * 0.4, r(N, h1, h2) * 0.08, r(N, h2) * 0.4, r(N, h2, nout) * 0.08, r(N, nout) * 0.4)
+        lo = BatchedMLP(*w, out_kind=ok, sample_kind=sk, precision="bf16", seed=3)
+        hi = BatchedMLP(*w, out_kind=ok, sample_kind=sk, precision="f32", seed=3)
+        y_lo, y_hi = host(lo.forward(x.cuda())), host(hi.forward(x.cuda()))
+        H.assert_close(y_lo, emul(x, w, act), f"bf16 vs emulation {h1}", rtol=2e-3, atol=2e-3)
+        assert np.abs(y_lo - y_hi).max() < 0.05 * max(1.0, np.abs(y_hi).max()), (h1, np.abs(y_lo - y_hi).max())
+        if sk == 1:
+            a_lo, i_lo = lo.sample_action(x.cuda()); a_hi, i_hi = hi.sample_action(x.cuda())
+            assert float((i_lo == i_hi).float().mean()) > 0.9           # same uniforms, nearly the same cdf

@@ -14,7 +14,7 @@ from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
 from tools.kbench import PRESETS
 
 
-def rnd_policy(kind, N, d, dev):
+def rnd_policy(kind, N, d, dev, precision="f32"):
     g = torch.Generator().manual_seed(1)
     r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * 0.2
     if kind == "softmax16":
@@ -23,7 +23,7 @@ def rnd_policy(kind, N, d, dev):
         h1 = h2 = 400; nout = 4; ok, sk = 2, 2
     else:
         h1 = h2 = 200; nout = 1; ok, sk = 0, 0
-    return BatchedMLP(r(N, d, h1), r(N, h1), r(N, h1, h2), r(N, h2), r(N, h2, nout), r(N, nout), ok, sk, device=dev), (h1, h2, nout)
+    return BatchedMLP(r(N, d, h1), r(N, h1), r(N, h1, h2), r(N, h2), r(N, h2, nout), r(N, nout), ok, sk, device=dev, precision=precision), (h1, h2, nout)
 
 
 def timeit(fn, steps=20, reps=5):
@@ -44,12 +44,12 @@ def timeit(fn, steps=20, reps=5):
 for spec in (sys.argv[1:] or ["c3", "c2", "c5"]):
     N, E, G, delta = PRESETS[spec]
     env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1)
-    for kind in ("softmax16", "gaussian", "critic"):
-        pol, (h1, h2, nout) = rnd_policy(kind, N, 6, env.device)
+    for kind, prec in [(k, p) for p in ("f32", "bf16") for k in ("softmax16", "gaussian", "critic")]:
+        pol, (h1, h2, nout) = rnd_policy(kind, N, 6, env.device, prec)
         z = env.z
         flops = 2.0 * E * N * (6 * h1 + h1 * h2 + h2 * nout)
         us = timeit((lambda: pol.sample_action(z)) if pol.sample_kind else (lambda: pol.forward(z)))
-        line = f"{spec} {kind:>9}: policy {us:8.1f} us/step = {flops/us/1e6:6.1f} TFLOP/s f32"
+        line = f"{spec} {kind:>9} {prec:>4}: policy {us:8.1f} us/step = {flops/us/1e6:6.1f} TFLOP/s"
         if pol.sample_kind:
             def loop():
                 act, _ = pol.sample_action(env.z, env=env)
