@@ -27,14 +27,15 @@ def run(spec, steps=200, reps=20):
         G, delta = float(G), float(delta)
     env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1)
     g = torch.Generator(device="cuda").manual_seed(0)
-    pool = torch.rand(steps, E, N, 2, device="cuda", generator=g) * 2 - 1
+    npool = int(os.environ.get("KB_POOL", steps))
+    pool = torch.rand(npool, E, N, 2, device="cuda", generator=g) * 2 - 1
     for s in range(10):
-        env.step(pool[s])
+        env.step(pool[s % npool])
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         for s in range(steps):
-            env.step(pool[s])
+            env.step(pool[s % npool])
     graph.replay(); torch.cuda.synchronize()
     env.reset(renew_obstacles=False)
     times = []
