@@ -65,10 +65,13 @@ typedef struct DroneParams {
     float ghost_factor;     /* 1.1                                                  */
     /* host-known bounds of the arrays below (the library never reads device
        memory on the host): used to pick the kernel variant and the early-out
-       radius.  0 < d_hat_min <= d_hat_max required.                                */
+       radius; when min == max for all three, the kernels take the constants from
+       here instead of reading the arrays.  0 < d_hat_min <= d_hat_max required.    */
     float d_hat_min;
     float d_hat_max;
+    float delta_min;
     float delta_max;
+    float radius_min;
     float radius_max;
     const float *xF;        /* [N][2] */
     const float *d_hat;     /* [N]    */

@@ -30,7 +30,8 @@ class DroneParams(C.Structure):
     _fields_ = [("N", C.c_int32), ("k", C.c_int32), ("c", C.c_int32), ("max_steps", C.c_int32),
                 ("dt", C.c_float), ("q", C.c_float), ("b", C.c_float),
                 ("done_radius", C.c_float), ("ghost_factor", C.c_float),
-                ("d_hat_min", C.c_float), ("d_hat_max", C.c_float), ("delta_max", C.c_float), ("radius_max", C.c_float),
+                ("d_hat_min", C.c_float), ("d_hat_max", C.c_float), ("delta_min", C.c_float), ("delta_max", C.c_float),
+                ("radius_min", C.c_float), ("radius_max", C.c_float),
                 ("xF", C.c_void_p), ("d_hat", C.c_void_p), ("delta", C.c_void_p),
                 ("radius", C.c_void_p)]
 

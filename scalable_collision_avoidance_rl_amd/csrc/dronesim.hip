@@ -68,6 +68,8 @@ struct KArgs {
     uint8_t *done;
     const uint8_t *mask;
     float skin;                     // rollout, kSym64: slack radius of the register-resident candidate list
+    int uniform;                    // all agents share d_hat, Delta and radius (host-known): constants come
+    float dhat_u, delta_u, radius_u;   //   from the kernel arguments, no per-agent table is read
 };
 
 // (d, j) as ONE unsigned key whose integer order is the lexicographic order of the pair:
@@ -218,9 +220,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             if (agent == 0) tcur = a.t[env];
         }
         const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
-        dhat = a.d_hat[(unsigned)agent];
-        delta_i = a.delta[(unsigned)agent];
-        li = a.radius[(unsigned)agent];
+        if (a.uniform) {
+            dhat = a.dhat_u; delta_i = a.delta_u; li = a.radius_u;
+        } else {
+            dhat = a.d_hat[(unsigned)agent];
+            delta_i = a.delta[(unsigned)agent];
+            li = a.radius[(unsigned)agent];
+        }
         xi = p.x; yi = p.y;
         xFx = g.x; xFy = g.y;
     }
@@ -244,12 +250,18 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     const int nbw = (N / 2 + 31) >> 5;
     unsigned *sback = sstage + (size_t)nwaves * kWave * (kZRow + kNRow);                   // [N][nbw]
 
+    // (Delta_j, l_j) of a partner: kernel-argument scalars when all agents share them -- except in the fused
+    // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
+    const bool uni_args = MODE != kRollout && a.uniform != 0;
     if (WL) {
         if ((int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;
-        if ((int)lane < N) sconst[lane] = make_float2(a.delta[lane], a.radius[lane]);
+        if (!uni_args && (int)lane < N)
+            sconst[lane] = a.uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[lane], a.radius[lane]);
     } else {
         if (tid < 2) sred[tid] = 0;
-        for (int s = tid; s < N; s += blockDim.x) sconst[s] = make_float2(a.delta[s], a.radius[s]);
+        if (!uni_args)
+            for (int s = tid; s < N; s += blockDim.x)
+                sconst[s] = a.uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[s], a.radius[s]);
         if (SYMB) for (int s = tid; s < N * nbw; s += blockDim.x) sback[s] = 0u;
     }
 
@@ -310,7 +322,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         auto visit = [&](int jdup) {
             const float2 pj = spos_env[jdup];
             const int j = jdup - ((jdup >= N) ? N : 0);
-            const float2 cj = sconst[j];                                      // (Delta_j, l_j)
+            const float2 cj = uni_args ? make_float2(a.delta_u, a.radius_u) : sconst[j];   // (Delta_j, l_j)
             const float dx = xi - pj.x, dy = yi - pj.y;
             const float d2 = fmaf(dy, dy, dx * dx);
             if (CACHED && !(d2 < thr)) return;                                // listed but currently far
@@ -484,7 +496,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         } else if (have[kth]) {                               // :367 / :385
                             const unsigned j = (unsigned)list[kth];
                             const float2 vj = reinterpret_cast<const float2 *>(velsrc)[(size_t)env * N + j];
-                            row[2] = vj.x; row[3] = vj.y; row[4] = sconst[j].y;
+                            row[2] = vj.x; row[3] = vj.y; row[4] = uni_args ? a.radius_u : sconst[j].y;
                         } else {
                             row[2] = row[3] = row[4] = __builtin_nanf("");
                         }
@@ -882,6 +894,11 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     a.dt = p->dt; a.q = p->q; a.b = p->b; a.done_radius = p->done_radius;
     a.ghost_factor = p->ghost_factor; a.radius_max = p->radius_max;
     a.reach_max = p->d_hat_max + 2.0f * p->radius_max;
+    a.uniform = (p->d_hat_min == p->d_hat_max && p->delta_min == p->delta_max && p->radius_min == p->radius_max) ? 1 : 0;
+    a.dhat_u = p->d_hat_max; a.delta_u = p->delta_max; a.radius_u = p->radius_max;
+#if defined(DRONESIM_NO_UNIFORM)
+    a.uniform = 0;
+#endif
     a.xF = p->xF; a.d_hat = p->d_hat; a.delta = p->delta; a.radius = p->radius;
     // far agents matter when a z row carries (v, l) of a tie-ordered agent (c = 5) or
     // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)

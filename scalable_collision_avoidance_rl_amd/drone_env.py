@@ -215,7 +215,9 @@ class drones:
             # float32 images of the arrays (what the kernel compares) bound the variant choice
             p.d_hat_min = float(self._d_hat.min().item())
             p.d_hat_max = float(self._d_hat.max().item())
+            p.delta_min = float(self._delta.min().item())
             p.delta_max = float(self._delta.max().item())
+            p.radius_min = float(self._radius.min().item())
             p.radius_max = float(self._radius.max().item())
             p.xF, p.d_hat = self._xF.data_ptr(), self._d_hat.data_ptr()
             p.delta, p.radius = self._delta.data_ptr(), self._radius.data_ptr()

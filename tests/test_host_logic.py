@@ -60,7 +60,7 @@ def test_shard_range_partitions_env_axis():
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _native.lib()
     header = open(_native.HEADER_PATH).read()
-    declared = sorted(set(re.findall(r"\b(dronesim_[a-z_]+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"\b(dronesim_[a-z0-9_]+)\s*\(", header)))
     assert declared == sorted(_native.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
@@ -74,7 +74,7 @@ def test_params_struct_layout_matches_header():
     body = header[header.index("typedef struct DroneParams {"):header.index("} DroneParams;")]
     names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|float)\s*\*?\s*(\w+);", body, re.M)
     assert names == [f[0] for f in _native.DroneParams._fields_]
-    assert C.sizeof(_native.DroneParams) == 4 * 4 + 9 * 4 + 4 + 4 * 8      # 4-byte pad before the pointers
+    assert C.sizeof(_native.DroneParams) == 4 * 4 + 11 * 4 + 4 + 4 * 8     # 4-byte pad before the pointers
 
 
 def test_argument_errors_are_reported_without_a_gpu():
