@@ -539,8 +539,23 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #else
         if (staged && nval > 0) {
 #endif
-            wave_copy_out(reinterpret_cast<unsigned *>(a.z) + (so + wga0) * kZRow, stage_z, nval * kZRow, lane);
-            wave_copy_out(reinterpret_cast<unsigned *>(a.nbr_idx) + (so + wga0) * kNRow, stage_n, nval * kNRow, lane);
+            unsigned *gz = reinterpret_cast<unsigned *>(a.z) + (so + wga0) * kZRow;
+            unsigned *gn = reinterpret_cast<unsigned *>(a.nbr_idx) + (so + wga0) * kNRow;
+            if (SYM) {
+                // full wave of one env, 16-byte aligned rows (checked on the host): fixed-shape copy, no loops
+                constexpr int nz = kWave * kZRow, nn = kWave * kNRow;          // words
+#pragma unroll
+                for (int o = 0; o < nz; o += 4 * kWave)
+                    if (o + 4 * kWave <= nz || (int)lane * 4 < nz - o)
+                        st_out(reinterpret_cast<u32x4 *>(gz + o) + lane, reinterpret_cast<const u32x4 *>(stage_z + o)[lane]);
+#pragma unroll
+                for (int o = 0; o < nn; o += 4 * kWave)
+                    if (o + 4 * kWave <= nn || (int)lane * 4 < nn - o)
+                        st_out(reinterpret_cast<u32x4 *>(gn + o) + lane, reinterpret_cast<const u32x4 *>(stage_n + o)[lane]);
+            } else {
+                wave_copy_out(gz, stage_z, nval * kZRow, lane);
+                wave_copy_out(gn, stage_n, nval * kNRow, lane);
+            }
         }
         if (valid && agent == 0) {
             const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
@@ -850,14 +865,26 @@ int check_params(const DroneParams *p, int E)
     return DRONESIM_OK;
 }
 
+// more than 64 KiB of dynamic LDS (envs of several hundred agents) has to be opted into once per kernel
+template <int K, bool FAR, int MODE, int GEO>
+void launch_one(const KArgs &a, const Geometry &g, hipStream_t s)
+{
+    static bool big_lds = false;
+    if (g.lds > 48 * 1024 && !big_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(drone_kernel<K, FAR, MODE, GEO>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        big_lds = true;
+    }
+    hipLaunchKernelGGL((drone_kernel<K, FAR, MODE, GEO>), dim3(g.blocks), dim3(g.threads), g.lds, s, a);
+}
+
 template <int K, bool FAR, int GEO>
 void launch_mode(int mode, const KArgs &a, const Geometry &g, hipStream_t s)
 {
-    const dim3 grid(g.blocks), block(g.threads);
     switch (mode) {
-    case kStep: hipLaunchKernelGGL((drone_kernel<K, FAR, kStep, GEO>), grid, block, g.lds, s, a); break;
-    case kObserve: hipLaunchKernelGGL((drone_kernel<K, FAR, kObserve, GEO>), grid, block, g.lds, s, a); break;
-    default: hipLaunchKernelGGL((drone_kernel<K, FAR, kRollout, GEO>), grid, block, g.lds, s, a); break;
+    case kStep: launch_one<K, FAR, kStep, GEO>(a, g, s); break;
+    case kObserve: launch_one<K, FAR, kObserve, GEO>(a, g, s); break;
+    default: launch_one<K, FAR, kRollout, GEO>(a, g, s); break;
     }
 }
 
@@ -886,6 +913,7 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     if (E == 0) return DRONESIM_OK;
     Geometry g = geometry(p->N, E);
     g.lds = drone_lds_bytes(g, p->N, p->k);
+    if (g.lds > 160 * 1024) return fail(DRONESIM_EUNSUPPORTED, "n_agents x k_closest too large for the 160 KiB LDS tile");
     a.N = p->N; a.c = p->c; a.max_steps = p->max_steps; a.E = E;
     a.P = g.P; a.epb = g.epb;
 #if defined(DRONESIM_TRACE)
@@ -904,7 +932,8 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)
     const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
 #if !defined(DRONESIM_NO_SYM64)
-    if (p->N == 64 && !far && p->d_hat_max >= p->d_hat_min) g.geo = kSym64;
+    if (p->N == 64 && !far && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
+        g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (p->k) {

@@ -167,6 +167,8 @@ CONFIGS = [
     ("n13_k8_hetero",  13,  12.0, 8, 2, "hetero",      515,  5.0),
     ("n65_k3",         65,  32.0, 3, 2, 1.0,           130,  12.0),
     ("n300_k2_c5",     300, 300.0, 2, 5, 2.0,          24,   40.0),
+    ("n700_k4",        700, 700.0, 4, 2, 2.0,          5,    90.0),     # > 64 KiB of LDS per workgroup
+    ("n1024_k2",       1024, 1024.0, 2, 2, 2.0,        3,    120.0),    # largest env: 16 waves, 141 KiB of LDS
 ]
 
 
@@ -734,3 +736,23 @@ def test_batched_policy_bf16_variant(torch):
         if sk == 1:
             a_lo, i_lo = lo.sample_action(x.cuda()); a_hi, i_hi = hi.sample_action(x.cuda())
             assert float((i_lo == i_hi).float().mean()) > 0.9           # same uniforms, nearly the same cdf
+
+
+def test_work_is_enqueued_on_the_callers_stream(torch):
+    """The library launches on the stream it is handed (torch's current stream): stepping inside a side
+    stream is ordered after work queued there and produces the same result."""
+    N, G, E = 64, 28.0, 256
+    a = make_env(N, G, 2, 2, np.ones(N), E, seed=1)
+    b = make_env(N, G, 2, 2, np.ones(N), E, seed=1)
+    side = torch.cuda.Stream()
+    act = torch.rand(E, N, 2, device="cuda:0") * 2 - 1
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        scaled = act * 0.5                      # producer on the side stream ...
+        torch.cuda._sleep(2_000_000)            # ... still busy when the step is enqueued behind it
+        a.step(scaled)
+    side.synchronize()
+    b.step(act * 0.5)
+    torch.cuda.synchronize()
+    for name in ("pos", "reward", "z", "nbr_idx", "n_coll", "done"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
