@@ -260,11 +260,13 @@ __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
 // W^T (A operand, pre-packed per fragment on the host, one 16-byte load per lane) x activations (B operand,
 // LDS, [row][k] row-major, one ds_read_b128 per lane) -- so that a lane's 4 consecutive accumulator
 // registers are 4 consecutive features of ONE env row and leave as one packed 8-byte LDS store.
-// One workgroup = 128 env rows of one agent (4 row tiles share every weight fragment), 4 waves, wave w owns
-// feature chunks w, w+4, ...  LDS row strides are odd multiples of 16 bytes (conflict-free b128 reads).
+// One workgroup = 64 env rows (2 row tiles sharing every weight fragment) of one agent, 4 waves; wave w owns
+// feature chunks w, w+4, ...  63 KiB of LDS per workgroup keeps two workgroups per CU resident, so one's
+// prologue / epilogue / barriers overlap the other's MFMAs.
+// LDS row strides are odd multiples of 16 bytes (conflict-free b128 reads).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int kRowsB = 128, kTiles = 4;
+constexpr int kRowsB = 64, kTiles = 2;        // 64 env rows (2 row tiles) per workgroup: 63 KiB of LDS, two workgroups per CU
 constexpr int kLdx = 24, kLds = 40;      // bf16 per row of the x tile / of a staged 32-feature chunk
 
 struct MArgsB {
@@ -274,57 +276,84 @@ struct MArgsB {
     FinishArgs fin;
 };
 
-// acc[t] += W^T chunk (k-steps [0, ks)) x activation rows of tile t
+// acc[t] += W^T chunk (k-steps [0, ks)) x activation rows of tile t.
+// One wave per SIMD has nobody to hide latency behind, so operands are fetched one stage (2 k-steps:
+// 2 weight fragments from L2, 8 activation fragments from LDS) ahead of the 8 MFMAs that consume them,
+// ping-ponging between two register sets.
+struct StageB { bf16x8 a[2]; bf16x8 b[2][kTiles]; };
+
+__device__ __forceinline__ void load_stage(StageB &st, const bf16x8 *__restrict__ wfrag, const __bf16 *brow, int ld,
+                                           int s, int lane)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        st.a[h] = wfrag[(size_t)(s + h) * 64 + lane];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)
+            st.b[h][t] = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + (s + h) * 16);
+    }
+}
+
+__device__ __forceinline__ void mma_stage(f32x16 (&acc)[kTiles], const StageB &st)
+{
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.a[h], st.b[h][t], acc[t], 0, 0, 0);
+}
+
 __device__ __forceinline__ void chunk_gemm(f32x16 (&acc)[kTiles], const bf16x8 *__restrict__ wfrag, int ks,
                                            const __bf16 *act, int ld, int lane)
 {
     const __bf16 *brow = act + (lane & 31) * ld + 8 * (lane >> 5);
-    int s = 0;
-    for (; s + 2 <= ks; s += 2) {                          // two k-steps in flight
-        const bf16x8 a0 = wfrag[(size_t)s * 64 + lane], a1 = wfrag[(size_t)(s + 1) * 64 + lane];
-        bf16x8 b0[kTiles], b1[kTiles];
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            b0[t] = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + s * 16);
-            b1[t] = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + s * 16 + 16);
+    const int kse = ks & ~1;                               // whole stages
+    if (kse > 0) {
+        StageB p, q;
+        load_stage(p, wfrag, brow, ld, 0, lane);
+        int s = 0;
+        while (true) {
+            if (s + 2 < kse) load_stage(q, wfrag, brow, ld, s + 2, lane);
+            mma_stage(acc, p);
+            s += 2;
+            if (s >= kse) break;
+            if (s + 2 < kse) load_stage(p, wfrag, brow, ld, s + 2, lane);
+            mma_stage(acc, q);
+            s += 2;
+            if (s >= kse) break;
         }
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0[t], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[t], acc[t], 0, 0, 0);
     }
-    for (; s < ks; ++s) {
-        const bf16x8 a0 = wfrag[(size_t)s * 64 + lane];
+    if (ks & 1) {                                          // odd tail (layer 1: a single k-step)
+        const bf16x8 a0 = wfrag[(size_t)kse * 64 + lane];
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) {
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + s * 16);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + kse * 16);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[t], 0, 0, 0);
         }
     }
 }
 
-// relu(acc + bias) of one 32-feature chunk -> bf16 rows [row][feature] (features >= nvalid are written as 0)
-__device__ __forceinline__ void store_chunk(const f32x16 (&acc)[kTiles], const float *__restrict__ bias, int f0, int nvalid,
-                                            __bf16 *dst, int ld, int lane)
+// relu(acc + bias) of one 32-feature chunk -> bf16 rows [row][feature].  `bias` points at the chunk's 32 biases
+// in LDS (zero beyond the layer width; the padded weights are zero there too, so those features come out 0).
+__device__ __forceinline__ void store_chunk(const f32x16 (&acc)[kTiles], const float *bias, __bf16 *dst, int ld, int lane)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int fl = 8 * q + 4 * (lane >> 5);            // local feature of register 4q (C/D layout rows)
-        float bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = (f0 + fl + i) < nvalid ? bias[f0 + fl + i] : 0.0f;
+        const float4 bv = *reinterpret_cast<const float4 *>(bias + fl);
 #pragma unroll
         for (int t = 0; t < kTiles; ++t) {
             bf16x4 p;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                p[i] = (__bf16)((f0 + fl + i) < nvalid ? fmaxf(acc[t][4 * q + i] + bv[i], 0.0f) : 0.0f);
+            p[0] = (__bf16)fmaxf(acc[t][4 * q + 0] + bv.x, 0.0f);
+            p[1] = (__bf16)fmaxf(acc[t][4 * q + 1] + bv.y, 0.0f);
+            p[2] = (__bf16)fmaxf(acc[t][4 * q + 2] + bv.z, 0.0f);
+            p[3] = (__bf16)fmaxf(acc[t][4 * q + 3] + bv.w, 0.0f);
             *reinterpret_cast<bf16x4 *>(dst + (t * 32 + (lane & 31)) * ld + fl) = p;
         }
     }
 }
 
-__global__ void __launch_bounds__(256) mlp3_bf16_kernel(const MArgsB a)
+__global__ void __launch_bounds__(256, 2) mlp3_bf16_kernel(const MArgsB a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -332,9 +361,10 @@ __global__ void __launch_bounds__(256) mlp3_bf16_kernel(const MArgsB a)
     const int agent = blockIdx.y;
     const int e0 = blockIdx.x * kRowsB;
     const int ld1 = a.nc1 * 32 + 8;
-    __bf16 *sx = reinterpret_cast<__bf16 *>(smem);                 // [128][24]
-    __bf16 *sst = sx + kRowsB * kLdx;                              // [4 waves][128][40]
-    __bf16 *sh1 = sst + 4 * kRowsB * kLds;                         // [128][ld1]; later the f32 partials [4][128][33]
+    __bf16 *sx = reinterpret_cast<__bf16 *>(smem);                 // [64][24]
+    __bf16 *sst = sx + kRowsB * kLdx;                              // [4 waves][64][40]
+    float *sbias = reinterpret_cast<float *>(sst + 4 * kRowsB * kLds);   // [nc1*32 + nc2*32] zero-padded biases
+    __bf16 *sh1 = reinterpret_cast<__bf16 *>(sbias + (a.nc1 + a.nc2) * 32);   // [64][ld1]; later f32 partials [4][64][33]
     float *spart = reinterpret_cast<float *>(sh1);
 
     for (int idx = tid; idx < kRowsB * 16; idx += 256) {           // x tile, zero padded to k = 16
@@ -343,13 +373,18 @@ __global__ void __launch_bounds__(256) mlp3_bf16_kernel(const MArgsB a)
         const float v = (c < a.d_in && e < a.E) ? a.x[((size_t)e * a.N + agent) * a.d_in + c] : 0.0f;
         sx[r * kLdx + c] = (__bf16)v;
     }
+    for (int idx = tid; idx < (a.nc1 + a.nc2) * 32; idx += 256) {  // biases once, so no epilogue waits on L2
+        const int f = idx < a.nc1 * 32 ? idx : idx - a.nc1 * 32;
+        sbias[idx] = idx < a.nc1 * 32 ? (f < a.h1 ? a.b1[(size_t)agent * a.h1 + f] : 0.0f)
+                                      : (f < a.h2 ? a.b2[(size_t)agent * a.h2 + f] : 0.0f);
+    }
     __syncthreads();
 
-    // ---- layer 1 -> sh1 (bf16)
+    // ---- layer 1 -> sh1 (bf16): wave w owns feature chunks w, w+4, ...
     for (int c = wave; c < a.nc1; c += 4) {
         f32x16 acc[kTiles] = {};
         chunk_gemm(acc, a.w1p + ((size_t)agent * a.nc1 + c) * a.ks1 * 64, a.ks1, sx, kLdx, lane);
-        store_chunk(acc, a.b1 + (size_t)agent * a.h1, c * 32, a.h1, sh1 + c * 32, ld1, lane);
+        store_chunk(acc, sbias + c * 32, sh1 + c * 32, ld1, lane);
     }
     __syncthreads();
 
@@ -360,7 +395,7 @@ __global__ void __launch_bounds__(256) mlp3_bf16_kernel(const MArgsB a)
     for (int c = wave; c < a.nc2; c += 4) {
         f32x16 acc[kTiles] = {};
         chunk_gemm(acc, a.w2p + ((size_t)agent * a.nc2 + c) * ks2 * 64, ks2, sh1, ld1, lane);
-        store_chunk(acc, a.b2 + (size_t)agent * a.h2, c * 32, a.h2, st, kLds, lane);
+        store_chunk(acc, sbias + (a.nc1 + c) * 32, st, kLds, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -442,7 +477,8 @@ extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, 
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
     const size_t sh1_bytes = sizeof(__bf16) * kRowsB * ((size_t)a.nc1 * 32 + 8);
     const size_t part_bytes = sizeof(float) * 4 * kRowsB * 33;
-    const size_t lds = sizeof(__bf16) * (kRowsB * kLdx + 4 * kRowsB * kLds) + (sh1_bytes > part_bytes ? sh1_bytes : part_bytes);
+    const size_t lds = sizeof(__bf16) * (kRowsB * kLdx + 4 * kRowsB * kLds) + sizeof(float) * 32 * (a.nc1 + a.nc2) +
+                       (sh1_bytes > part_bytes ? sh1_bytes : part_bytes);
     static bool big_lds_enabled = false;
     if (!big_lds_enabled) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
