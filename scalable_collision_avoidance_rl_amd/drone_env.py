@@ -316,12 +316,9 @@ class drones:
         if self.batched:
             return self._result
         self._sync_host_views()
-        r = self.reward[0].double().cpu().numpy()
-        tr = self.true_reward[0].double().cpu().numpy()
-        n_coll = np.int64(self.n_coll[0].item())
-        finished = bool(self.done[0].item())
         self.internal_t += 1
-        return self.state, self.z_states, r, n_coll, finished, tr
+        return (self.state, self.z_states, self._host_reward, self._host_n_coll, self._host_done,
+                self._host_true_reward)
 
     def rollout(self, actions, with_pre=False):
         """T fused steps in one launch with the actions known up front (RandomAgent-style rollouts,
@@ -417,23 +414,38 @@ class drones:
 
     # ------------------------------------------------------------------ compat-mode host views
     def _sync_host_views(self):
-        """E == 1 compat: mirror device state/observation into the reference's Python types."""
+        """E == 1 compat: mirror device state/observation into the reference's Python types.
+        Everything the reference returns per step travels in ONE device-to-host copy."""
         if self.batched:
             return
+        torch = self._torch
         N, K1, c = self.n_agents, self.k_closest + 1, self.c
+        flat = torch.cat([self.pos.view(-1), self.vel.view(-1), self.z.view(-1), self.reward.view(-1),
+                          self.true_reward.view(-1), self.nbr_idx.view(-1).float(), self.n_coll.float(),
+                          self.done.float()]).double().cpu().numpy()
+        o = 0
+
+        def take(n):
+            nonlocal o
+            out = flat[o:o + n]; o += n
+            return out
         st = np.empty((N, 5))
-        st[:, 0:2] = self.pos[0].double().cpu().numpy()
-        st[:, 2:4] = self.vel[0].double().cpu().numpy()
+        st[:, 0:2] = take(2 * N).reshape(N, 2)
+        st[:, 2:4] = take(2 * N).reshape(N, 2)
         st[:, 4] = self.drone_radius
         if getattr(self, "state", None) is None or self.state.shape != st.shape:
             self.state = st
         else:
             self.state[...] = st                      # keep the same live array object (drone_env.py:258)
         self._state_pushed = self.state.copy()
-        z = self.z[0].double().cpu().numpy().reshape(N, K1, c)
-        nb = self.nbr_idx[0].cpu().numpy()
+        z = take(N * K1 * c).reshape(N, K1, c)
+        self._host_reward = take(N).copy()
+        self._host_true_reward = take(N).copy()
+        nb = take(N * K1).astype(np.int64).reshape(N, K1)
+        self._host_n_coll = np.int64(take(1)[0])
+        self._host_done = bool(take(1)[0])
         self.z_states = [z[i].copy() for i in range(N)]
-        self.Ni = [[int(i)] + [np.int64(j) for j in nb[i, 1:] if j >= 0] for i in range(N)]
+        self.Ni = [[int(i)] + [j for j in nb[i, 1:] if j >= 0] for i in range(N)]
 
     def _push_host_state(self):
         """Callers may write into env.state / env.internal_t between steps (the reference's state is a
