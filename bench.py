@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--policy", default="random", choices=["random", "softmax16", "gaussian"],
                     help="action source: pre-generated U(-1,1) actions (the graded workload) or a batched per-agent "
                          "policy evaluated on the env's observation every step (BASELINE configs[4] uses 'gaussian')")
+    ap.add_argument("--policy-precision", default="f32", choices=["f32", "bf16"],
+                    help="matrix-core arithmetic of the batched policy (f32 = exact, bf16 = opt-in fast path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -139,7 +141,7 @@ def main():
         rw = lambda *sh: (torch.rand(*sh, generator=gp) * 2 - 1) * 0.2
         h, nout, ok, sk = (300, 16, 1, 1) if args.policy == "softmax16" else (400, 4, 2, 2)   # utils.py:255-302 / 55-108
         policy = BatchedMLP(rw(N, 6, h), rw(N, h), rw(N, h, h), rw(N, h), rw(N, h, nout), rw(N, nout), ok, sk,
-                            device=dev, seed=1234)
+                            device=dev, seed=1234, precision=args.policy_precision)
 
     def one_step(s):
         if policy is None:
@@ -241,7 +243,7 @@ def main():
                        "grid": G, "delta": delta, "k_closest": 2, "simplify_zstate": True,
                        "launch": "hipGraph replay (200 steps + reset per graph)" if graph is not None else "eager",
                        "actions": "pre-generated U(-1,1)^2, resident in HBM" if policy is None else
-                                  f"batched per-agent {args.policy} policy (random-init, exact-f32 MFMA) on the observation",
+                                  f"batched per-agent {args.policy} policy (random-init, {args.policy_precision} MFMA) on the observation",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -332,11 +332,12 @@ def test_reset_matches_oracle_bit_exact_and_shards(torch):
 
 
 # ------------------------------------------------------------------------------- rollout / determinism
-@pytest.mark.parametrize("N,G,E,T", [(5, 5.0, 100, 12), (64, 28.0, 64, 8), (130, 130.0, 6, 5)])
-def test_rollout_equals_sequential_steps(torch, N, G, E, T):
+@pytest.mark.parametrize("N,G,E,T,c", [(5, 5.0, 100, 12, 2), (64, 28.0, 64, 8, 2), (130, 130.0, 6, 5, 2),
+                                         (64, 28.0, 33, 7, 5), (9, 8.0, 50, 9, 5)])
+def test_rollout_equals_sequential_steps(torch, N, G, E, T, c):
     """dronesim_rollout (T steps in one launch) is bit-identical to T dronesim_step launches."""
-    a = make_env(N, G, 2, 2, np.ones(N), E, seed=9)
-    b = make_env(N, G, 2, 2, np.ones(N), E, seed=9)
+    a = make_env(N, G, 2, c, np.ones(N), E, seed=9)
+    b = make_env(N, G, 2, c, np.ones(N), E, seed=9)
     assert torch.equal(a.pos, b.pos)
     a.t.fill_(195); b.t.fill_(195)
     g = torch.Generator(device="cuda:0").manual_seed(1)
