@@ -112,78 +112,69 @@ __device__ __forceinline__ void finish_row(const FinishArgs &a, float (&y)[kMaxO
     }
 }
 
-// (acc0, acc1) += A[64 x K] * B[K x 32] for the two 32-row halves of A, sharing every B fragment.
-// A row-major in LDS (lda floats per row, odd stride -> conflict-free), B row-major in global / L2 (ldb
-// floats per row); B columns >= ncols_valid and k >= K read as zero.  Operand loads of the next 8 k-steps
-// are issued before the 16 MFMAs of the current ones (software pipelining: one wave per SIMD has nobody
-// else to hide the L2 latency behind).
+// acc += A[32 x K] * B[K x 32].  A row-major in LDS (lda floats per row, odd stride -> conflict-free), B row-major
+// in global / L2 (ldb floats per row); B columns >= ncols_valid read a clamped column (never stored), k >= K reads
+// as zero.  Operand loads of the next 8 k-steps are issued before the 8 MFMAs of the current ones.
 constexpr int kU = 8;                  // k-steps (of 2) per pipeline stage
 
-struct Frag { float b[kU], a0[kU], a1[kU]; };
+struct Frag { float b[kU], a[kU]; };
 
-// branch-free: every k of the stage is < K and the column index is already clamped
-__device__ __forceinline__ void load_frag(Frag &f, const float *Arow0, const float *Arow1,
-                                          const float *__restrict__ Bcol, int ldb, int kbase)
+__device__ __forceinline__ void load_frag(Frag &f, const float *Arow, const float *__restrict__ Bcol, int ldb, int kbase)
 {
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
         const int k = kbase + 2 * u;
         f.b[u] = Bcol[(size_t)k * ldb];
-        f.a0[u] = Arow0[k];
-        f.a1[u] = Arow1[k];
+        f.a[u] = Arow[k];
     }
 }
 
-__device__ __forceinline__ void tile_gemm2(f32x16 &acc0, f32x16 &acc1, const float *A, int lda,
-                                           const float *__restrict__ B, int ldb, int K, int ncols_valid, int lane)
+__device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, const float *__restrict__ B, int ldb,
+                                          int K, int ncols_valid, int lane)
 {
     const int ar = lane & 31, kk = lane >> 5;
-    // columns beyond the matrix read a clamped (valid) column; their results are never stored
     const float *Bcol = B + min(ar, ncols_valid - 1);
-    const float *Arow0 = A + ar * lda, *Arow1 = A + (ar + 32) * lda;
+    const float *Arow = A + ar * lda;
     const int Kmain = K - K % (2 * kU);                    // whole pipeline stages, no bounds checks inside
     if (Kmain > 0) {
         Frag cur, nxt;
-        load_frag(cur, Arow0, Arow1, Bcol, ldb, kk);
+        load_frag(cur, Arow, Bcol, ldb, kk);
         for (int k0 = 0; k0 < Kmain; k0 += 2 * kU) {
             const bool more = k0 + 2 * kU < Kmain;         // wave-uniform
-            if (more) load_frag(nxt, Arow0, Arow1, Bcol, ldb, k0 + 2 * kU + kk);
+            if (more) load_frag(nxt, Arow, Bcol, ldb, k0 + 2 * kU + kk);
 #pragma unroll
-            for (int u = 0; u < kU; ++u) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a0[u], cur.b[u], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a1[u], cur.b[u], acc1, 0, 0, 0);
-            }
+            for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b[u], acc, 0, 0, 0);
             if (more) cur = nxt;
         }
     }
     for (int k0 = Kmain; k0 < K; k0 += 2) {                // tail (K not a multiple of 16)
         const int k = k0 + kk;
         const bool kok = k < K;
-        const float bv = kok ? Bcol[(size_t)k * ldb] : 0.0f;
-        const float a0 = kok ? Arow0[k] : 0.0f, a1 = kok ? Arow1[k] : 0.0f;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc1, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kok ? Arow[k] : 0.0f, kok ? Bcol[(size_t)k * ldb] : 0.0f, acc, 0, 0, 0);
     }
 }
 
-__global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
+// 64 env rows of one agent per workgroup, 8 waves = two per SIMD (one's operand loads hide behind the other's
+// MFMAs): wave w owns feature chunks (w & 3), (w & 3) + 4, ... for the 32 rows of half (w >> 2).
+__global__ void __launch_bounds__(512) mlp3_kernel(const MArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 3, rh = wave >> 2;
     const int agent = blockIdx.y;
     const int e0 = blockIdx.x * kRows;
     const int ldx = a.d_in + 1, ld1 = a.h1 + 1;
     float *sx = reinterpret_cast<float *>(smem);                 // [64][d_in+1]
     float *sh1 = sx + kRows * ldx;                               // [64][h1+1]
-    float *sst = sh1 + kRows * ld1;                              // [4 waves][64][33] layer-2 chunk staging,
+    float *sst = sh1 + kRows * ld1;                              // [8 waves][32][33] layer-2 chunk staging,
                                                                  // reused for the layer-3 partials
     const float *w1 = a.w1 + (size_t)agent * a.d_in * a.h1, *b1 = a.b1 + (size_t)agent * a.h1;
     const float *w2 = a.w2 + (size_t)agent * a.h1 * a.h2, *b2 = a.b2 + (size_t)agent * a.h2;
     const float *w3 = a.w3 + (size_t)agent * a.h2 * a.nout, *b3 = a.b3 + (size_t)agent * a.nout;
 
     // ---- x tile -> LDS (rows beyond E are zero)
-    for (int idx = tid; idx < kRows * a.d_in; idx += 256) {
+    for (int idx = tid; idx < kRows * a.d_in; idx += 512) {
         const int r = idx / a.d_in, c = idx - r * a.d_in;
         const int e = e0 + r;
         sx[r * ldx + c] = e < a.E ? a.x[((size_t)e * a.N + agent) * a.d_in + c] : 0.0f;
@@ -191,54 +182,46 @@ __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
     __syncthreads();
 
     const int col = lane & 31;
-    // ---- layer 1: wave w owns column chunks w, w+4, ... (all 64 rows)
-    for (int c0 = wave * 32; c0 < a.h1; c0 += 128) {
-        f32x16 acc0 = {0}, acc1 = {0};
-        tile_gemm2(acc0, acc1, sx, ldx, w1 + c0, a.h1, a.d_in, a.h1 - c0, lane);
+    // ---- layer 1
+    for (int c0 = cw * 32; c0 < a.h1; c0 += 128) {
+        f32x16 acc = {0};
+        tile_gemm(acc, sx + rh * 32 * ldx, ldx, w1 + c0, a.h1, a.d_in, a.h1 - c0, lane);
         const bool ok = c0 + col < a.h1;
         const float bias = ok ? b1[c0 + col] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            if (ok) {
-                sh1[cd_row(r, lane) * ld1 + c0 + col] = fmaxf(acc0[r] + bias, 0.0f);
-                sh1[(32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc1[r] + bias, 0.0f);
-            }
+            if (ok) sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc[r] + bias, 0.0f);
     }
     __syncthreads();
 
     // ---- layers 2 + 3 fused over this wave's column chunks
-    f32x16 y0 = {0}, y1 = {0};
-    float *st = sst + wave * 64 * 33;
-    for (int c0 = wave * 32; c0 < a.h2; c0 += 128) {
-        f32x16 acc0 = {0}, acc1 = {0};
-        tile_gemm2(acc0, acc1, sh1, ld1, w2 + c0, a.h2, a.h1, a.h2 - c0, lane);
+    f32x16 y = {0};
+    float *st = sst + wave * 32 * 33;
+    for (int c0 = cw * 32; c0 < a.h2; c0 += 128) {
         const bool ok = c0 + col < a.h2;
-        const float bias = ok ? b2[c0 + col] : 0.0f;
+        const float bias = ok ? b2[c0 + col] : 0.0f;             // issued before the k-loop, needed after it
+        f32x16 acc = {0};
+        tile_gemm(acc, sh1 + rh * 32 * ld1, ld1, w2 + c0, a.h2, a.h1, a.h2 - c0, lane);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            st[cd_row(r, lane) * 33 + col] = ok ? fmaxf(acc0[r] + bias, 0.0f) : 0.0f;
-            st[(32 + cd_row(r, lane)) * 33 + col] = ok ? fmaxf(acc1[r] + bias, 0.0f) : 0.0f;
-        }
+        for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = ok ? fmaxf(acc[r] + bias, 0.0f) : 0.0f;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int kc = min(32, a.h2 - c0);
-        tile_gemm2(y0, y1, st, 33, w3 + (size_t)c0 * a.nout, a.nout, kc, a.nout, lane);
+        tile_gemm(y, st, 33, w3 + (size_t)c0 * a.nout, a.nout, kc, a.nout, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {                               // this wave's partial outputs
-        st[cd_row(r, lane) * 33 + col] = y0[r];
-        st[(32 + cd_row(r, lane)) * 33 + col] = y1[r];
-    }
+    for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = y[r];   // this wave's partial outputs
     __syncthreads();
 
     // ---- output activation + sampling: one thread per env row
     if (tid < kRows) {
         const int e = e0 + tid;
         if (e >= a.E) return;
-        float y[kMaxOut];
+        const int rhh = tid >> 5, rr = tid & 31;
+        float yv[kMaxOut];
         const int nout = a.nout;
 #pragma unroll
         for (int j = 0; j < kMaxOut; ++j) {
@@ -246,11 +229,11 @@ __global__ void __launch_bounds__(256) mlp3_kernel(const MArgs a)
             if (j < nout) {
                 v = b3[j];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += sst[(w * 64 + tid) * 33 + j];
+                for (int w = 0; w < 4; ++w) v += sst[((rhh * 4 + w) * 32 + rr) * 33 + j];
             }
-            y[j] = v;
+            yv[j] = v;
         }
-        finish_row(a.fin, y, e, agent);
+        finish_row(a.fin, yv, e, agent);
     }
 }
 
@@ -507,7 +490,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2; a.nout = m->nout;
     a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
-    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + 4 * 64 * 33);
+    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + 8 * 32 * 33);
     static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
     if (!big_lds_enabled) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -516,7 +499,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
         big_lds_enabled = true;
     }
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
-    hipLaunchKernelGGL(mlp3_kernel, dim3((E + kRows - 1) / kRows, m->N), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(mlp3_kernel, dim3((E + kRows - 1) / kRows, m->N), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
