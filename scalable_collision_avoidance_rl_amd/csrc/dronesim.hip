@@ -10,20 +10,21 @@
 //   termination / t         drone_env.py:247-258
 //   reset / init_agents     drone_env.py:98-102, 171-212
 //
-// Work decomposition (one launch = one env.step() for E envs)
-//   N <= 64 : lane = agent; floor(64/N) envs are packed into one wave, 4 waves per
-//             workgroup.  N = 64 -> one wave per env, N = 5 -> 12 envs per wave.
+// Work decomposition (one launch = one env.step() for E envs); DESIGN.md section 3 has the measurements
+//   N <= 64 : lane = agent; floor(64/N) envs packed per wave, 4 independent waves per 256-thread
+//             workgroup, wave-local synchronisation only.  N = 64 -> one wave per env.
 //   N  > 64 : one workgroup per env, thread = agent (N <= 1024).
-//   The integrated positions of the workgroup's envs are staged once in LDS, stored
-//   TWICE back to back per env (x_0..x_{N-1}, x_0..x_{N-1}) so that lane i reads its
-//   r-th partner j = (i + r) mod N at the wrap-free address base_i + r: the unrolled
-//   pair loop has immediate offsets only, consecutive lanes hit consecutive banks
-//   (conflict-free ds_read_b64), and the self pair r = 0 is never visited.
-//   Pass 1 ("far filter", ~6 VALU/pair): squared distance against the row's
-//   early-out radius (dhat_i + l_i + l_max)^2.  A pair beyond it has d_ij = dhat_i,
-//   log term 0, no collision, and -- when max(Delta) < min(dhat), the regime of every
-//   config in BASELINE.json -- is outside every Delta mask, so it contributes nothing.
-//   Survivors are recorded as one bit per partner in a per-lane 32-bit mask.
+//   Every wave covers a contiguous range of global agents: streams are wave-uniform base + lane.
+//   LDS tile: the integrated positions of an env are stored TWICE back to back (x_0..x_{N-1},
+//   x_0..x_{N-1}) so that lane i reads its r-th partner j = (i + r) mod N at the wrap-free address
+//   base_i + r (immediate offsets, no self pair), in two copies one element apart so that every
+//   lane has a 16-byte aligned window (two partners per ds_read_b128).
+//   Pass 1 ("far filter", ~5 VALU/pair): squared distance against the early-out radius
+//   (dhat + l_i + l_max)^2.  A pair beyond it has d_ij = dhat_i, log term 0, no collision, and --
+//   when max(Delta) < min(dhat), the regime of every config in BASELINE.json -- is outside every
+//   Delta mask, so it contributes nothing.  Survivors become one bit per partner in a per-lane mask.
+//   Every unordered pair is scanned ONCE where that is possible: N = 64 hands the verdict to the
+//   other end as a rotated ballot (kSym64), N > 64 through an LDS bit table (SYMB).
 //   Pass 2 ("near pairs"): each lane walks ITS OWN set bits, so a wave spends
 //   max-over-lanes(popcount) iterations instead of one per partner; only here are
 //   sqrt / log / the Delta mask / the (k+1)-entry sorted neighbour list evaluated.
@@ -32,6 +33,8 @@
 //   semantics, slower).
 //   Ordering: the neighbour list is ordered by (d_ij, j) lexicographically = the
 //   first k+1 entries of a stable argsort of row i, independent of visiting order.
+//   Outputs: z rows / Ni are transposed through LDS and leave as full 128-byte lines; all outputs
+//   use streaming (non-temporal) stores.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
