@@ -758,3 +758,46 @@ def test_work_is_enqueued_on_the_callers_stream(torch):
     torch.cuda.synchronize()
     for name in ("pos", "reward", "z", "nbr_idx", "n_coll", "done"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_degenerate_states_follow_the_reference_semantics(torch):
+    """Corners the reference leaves unguarded: exactly coincident agents (gap == -2l ties
+    with the self entry; stable order = lowest index), an agent exactly on its goal (ghost rows are NaN,
+    drone_env.py:386), and a non-square grid."""
+    from scalable_collision_avoidance_rl_amd import drones
+    N, G = 6, 6.0
+    env = make_env(N, G, 2, 2, np.ones(N), 3)
+    orc = Oracle(N, [G, G], 2, np.ones(N), True)
+    pos = np.zeros((3, N, 2), np.float32)
+    rng = np.random.default_rng(4)
+    pos[:] = (G / 2 + (rng.random((3, N, 2)) - 0.5) * 5).astype(np.float32)
+    pos[0, 4] = pos[0, 1]                       # env 0: agents 1 and 4 coincide
+    pos[1, 2] = orc.xF[2].astype(np.float32)    # env 1: agent 2 sits exactly on its (float32) goal
+    env.set_state(pos)
+    torch.cuda.synchronize()
+    ref = orc.observe(pos.astype(np.float64))
+    nb, z = host(env.nbr_idx), host(env.z).reshape(3, N, 3, 2)
+    # coincident pair: each lists the other first; agent 4 sees agent 1 BEFORE itself in sorted order (tie on
+    # d = -0.2, lower index wins), so its first neighbour slot is itself-excluded entry 1 ... exactly as the oracle
+    np.testing.assert_array_equal(nb[0], ref["nbr_idx"][0])
+    assert host(env.n_coll)[0] == ref["n_coll"][0] >= 2
+    H.assert_close(host(env.reward)[0], ref["reward"][0], "coincident reward")
+    # on-goal agent: float32 goal == float32 position -> z_i = 0 -> NaN ghost rows on the GPU; the float64 oracle
+    # sees the float32-rounded goal a hair away, so only the GPU's own NaN pattern is asserted
+    zi = z[1, 2]
+    assert zi[0].tolist() == [0.0, 0.0]
+    ghost = nb[1, 2, 1:] < 0
+    assert np.isnan(zi[1:][ghost]).all() and np.isfinite(zi[1:][~ghost]).all()
+    assert np.isfinite(host(env.reward)[1]).all()
+    np.testing.assert_array_equal(nb[2], ref["nbr_idx"][2])
+    # non-square grid
+    env2 = drones(6, 0, [7, 4], "O", deltas=np.ones(6) * 0.8, simplify_zstate=True, n_envs=40, batched=True, seed=6)
+    orc2 = Oracle(6, [7, 4], 2, np.ones(6) * 0.8, True)
+    p = host(env2.pos)
+    assert p[..., 0].max() <= 7 and p[..., 1].max() <= 4 and p.min() >= 0
+    act = torch.rand(40, 6, 2, device="cuda:0") * 2 - 1
+    env2.step(act)
+    p1 = host(env2.pos).astype(np.float64)
+    ref2 = orc2.observe(p1, host(act).astype(np.float64))
+    safe = orc2.margins(p1) > H.MARGIN
+    check_outputs(env2, None, ref2, safe, 2, None, "grid 7x4 ")
