@@ -173,9 +173,13 @@ int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *a
 /* Opt-in bfloat16 variant of dronesim_mlp_forward (weights and activations in bf16, float32 accumulation,
  * ~16x the matrix rate; outputs agree with the float32 path to bf16 round-off, ~1e-2 relative).
  * Weights are pre-packed per matrix-core fragment: for a layer with K inputs and F outputs,
- *   wp[agent][c][s][lane][j] = W[16 s + 8 (lane >> 5) + j][32 c + (lane & 31)]   (0 beyond K or F)
- * for feature chunks c < ceil(F/32), k-steps s and j < 8, as bf16 (16 bytes per lane).  k-steps:
- * layer 1: 1 (d_in <= 16), layer 2: 2 ceil(h1/32), layer 3: 2 ceil(h2/32) with a single chunk (nout <= 32).  */
+ *   wp[agent][c][s][lane][j] = W[kmap(s, lane >> 5, j)][32 c + (lane & 31)]   (0 beyond K or F)
+ * for feature chunks c < ceil(F/32), k-steps s and j < 8, as bf16 (16 bytes per lane), with
+ *   layers 1, 2:  kmap(s, h, j) = 16 s + 8 h + j
+ *   layer 3:      kmap(s, h, j) = 16 s + 8 (j >> 2) + 4 h + (j & 3)   (the order in which a lane of the
+ *                 layer-2 accumulator tile holds its features, so layer 3 is fed from registers).
+ * k-steps: layer 1: 1 (d_in <= 16), layer 2: 2 ceil(h1/32), layer 3: 2 ceil(h2/32) with a single chunk
+ * (nout <= 32).  */
 typedef struct DroneMlpBf16 {
     int32_t N, d_in, h1, h2, nout, out_kind, sample_kind, reserved;
     const void *w1p, *w2p, *w3p;     /* packed bf16 fragments */

@@ -13,7 +13,7 @@
 //
 // Arithmetic: exact float32 on the matrix cores -- v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain
 // (no reduced precision), so results match a float32 torch reference to round-off.
-// Decomposition: grid = (ceil(E/64), N): one workgroup = 64 env rows of ONE agent, 4 waves.
+// Decomposition: ceil(E/64) x N workgroups (XCD-aware order, see xcd_work_item): one workgroup = 64 env rows of ONE agent.
 //   wave w owns every fourth 32-column chunk of the hidden layers for all 64 rows (two 32x32
 //   accumulators that share every B fragment).
 //   layer 1: A = x tile (LDS), B = W1 (global/L2)            -> h1 tile in LDS [64][h1+1]
@@ -48,65 +48,108 @@ struct MArgs {
     FinishArgs fin;
 };
 
+// Workgroup -> (agent, row block).  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs,
+// each with its own 4 MiB L2; all agents' weights together (12.8 MiB in bf16 / 23 MiB in f32 at N = 64,
+// h = 300) do not fit one L2, a few agents' do.  So the work list is ordered agent-major and cut into 8
+// contiguous pieces, one per XCD: XCD x walks its own agents one after the other, the ~64 workgroups resident
+// on it at any time share one or two agents' weights, and every weight byte leaves HBM once per launch.
+__device__ __forceinline__ void xcd_work_item(int row_blocks, int &agent, int &row_block)
+{
+    const int total = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int v = xcd * q + min(xcd, r) + slot;            // XCD x owns q + (x < r) items
+    agent = v / row_blocks;
+    row_block = v - agent * row_blocks;
+}
+
 // C/D layout of v_mfma_f32_32x32x2_f32: element reg r of lane l is (row = (r&3) + 8*(r>>2) + 4*(l>>5), col = l&31)
 __device__ __forceinline__ int cd_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
-// Output activation + sampling of ONE env row (y = pre-activation outputs of this row's agent network).
+// Output activation + sampling of ONE env row by the 4 adjacent lanes of a quad: lane `part` holds the
+// pre-activation outputs j = part + 4 i (i < 8) in y[i].  Reductions over the row (softmax max / sum, the
+// categorical cdf) run on DPP quad permutes, so the serial tail of the kernel is a quarter as long and the
+// probabilities leave as 16-byte segments.  tval / epval: the env's step and episode counters (0 if absent).
+constexpr int kQ = kMaxOut / 4;
 
-__device__ __forceinline__ void finish_row(const FinishArgs &a, float (&y)[kMaxOut], int e, int agent)
+template <int CTRL> __device__ __forceinline__ float quad_perm(float v)     // CTRL = quad_perm:[a,b,c,d] = a | b<<2 | c<<4 | d<<6
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kQuadXor1 = 0xB1, kQuadXor2 = 0x4E, kQuadUp1 = 0x90, kQuadUp2 = 0x40, kQuadLast = 0xFF;
+
+__device__ __forceinline__ void finish_quad(const FinishArgs &a, float (&y)[kQ], int e, int agent, int part,
+                                            uint32_t tval, uint32_t epval)
 {
     const int nout = a.nout;
     if (a.out_kind == 1) {                                   // softmax (utils.py:286, dim = 0 of one sample)
         float m = -__builtin_inff();
 #pragma unroll
-        for (int j = 0; j < kMaxOut; ++j) if (j < nout) m = fmaxf(m, y[j]);
+        for (int i = 0; i < kQ; ++i) if (part + 4 * i < nout) m = fmaxf(m, y[i]);
+        m = fmaxf(m, quad_perm<kQuadXor1>(m));
+        m = fmaxf(m, quad_perm<kQuadXor2>(m));
         float ssum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < kMaxOut; ++j) { y[j] = j < nout ? expf(y[j] - m) : 0.0f; ssum += y[j]; }
+        for (int i = 0; i < kQ; ++i) {
+            if (4 * i < nout) { y[i] = part + 4 * i < nout ? expf(y[i] - m) : 0.0f; ssum += y[i]; }
+            else y[i] = 0.0f;
+        }
+        ssum += quad_perm<kQuadXor1>(ssum);
+        ssum += quad_perm<kQuadXor2>(ssum);
         const float inv = 1.0f / ssum;
 #pragma unroll
-        for (int j = 0; j < kMaxOut; ++j) y[j] *= inv;
+        for (int i = 0; i < kQ; ++i) y[i] *= inv;
     } else if (a.out_kind == 2) {                            // tanh means, sigmoid variances (utils.py:74-77)
         const int half = nout / 2;
 #pragma unroll
-        for (int j = 0; j < kMaxOut; ++j)
-            if (j < nout) y[j] = j < half ? tanhf(y[j]) : 1.0f / (1.0f + expf(-y[j]));
+        for (int i = 0; i < kQ; ++i) {
+            const int j = part + 4 * i;
+            if (j < nout) y[i] = j < half ? tanhf(y[i]) : 1.0f / (1.0f + expf(-y[i]));
+        }
     }
     const size_t row = (size_t)e * a.N + agent;
     if (a.out) {
 #pragma unroll
-        for (int j = 0; j < kMaxOut; ++j) if (j < nout) a.out[row * nout + j] = y[j];
+        for (int i = 0; i < kQ; ++i) if (part + 4 * i < nout) a.out[row * nout + part + 4 * i] = y[i];
     }
     if (a.sample_kind != 0) {
         uint32_t rnd[4];
-        const uint32_t c2 = a.ctr2 + (a.t_dev ? (uint32_t)a.t_dev[e] : 0u);
-        const uint32_t c3 = a.ctr3 + (a.episode_dev ? (uint32_t)a.episode_dev[e] : 0u);
-        philox4x32_10((uint32_t)agent, (uint32_t)(a.env_base + e), c2, c3, a.key0, a.key1, rnd);
+        philox4x32_10((uint32_t)agent, (uint32_t)(a.env_base + e), a.ctr2 + tval, a.ctr3 + epval, a.key0, a.key1, rnd);
         if (a.sample_kind == 1) {                            // categorical -> unit vector (utils.py:262-269, 304-309)
             const float u = (float)(rnd[0] >> 8) * (1.0f / 16777216.0f);
-            float cdf = 0.0f;
-            int pick = nout - 1;
-            bool found = false;
+            float base = 0.0f;                               // cdf up to the previous group of 4 outputs
+            int below = 0;                                   // outputs j with cdf_j <= u: the pick is the first j with u < cdf_j
 #pragma unroll
-            for (int j = 0; j < kMaxOut; ++j) {
-                if (j < nout) {
-                    cdf += y[j];
-                    if (!found && u < cdf) { pick = j; found = true; }
+            for (int i = 0; i < kQ; ++i) {
+                if (4 * i < nout) {
+                    const bool valid = part + 4 * i < nout;
+                    float incl = valid ? y[i] : 0.0f;        // inclusive scan over the quad
+                    const float n1 = quad_perm<kQuadUp1>(incl);
+                    if (part >= 1) incl += n1;
+                    const float n2 = quad_perm<kQuadUp2>(incl);
+                    if (part >= 2) incl += n2;
+                    const float cdf = base + incl;
+                    if (valid && !(u < cdf)) ++below;
+                    base = quad_perm<kQuadLast>(cdf);
                 }
             }
-            if (a.act_idx) a.act_idx[row] = pick;
-            if (a.act) {
-                const float ang = (float)pick / (float)nout * 6.283185307179586f;
-                a.act[row * 2 + 0] = cosf(ang);
-                a.act[row * 2 + 1] = sinf(ang);
+            below += __builtin_amdgcn_update_dpp(0, below, kQuadXor1, 0xF, 0xF, true);
+            below += __builtin_amdgcn_update_dpp(0, below, kQuadXor2, 0xF, 0xF, true);
+            const int pick = min(below, nout - 1);
+            if (part == 0) {
+                if (a.act_idx) a.act_idx[row] = pick;
+                if (a.act) {
+                    const float ang = (float)pick / (float)nout * 6.283185307179586f;
+                    *reinterpret_cast<float2 *>(a.act + row * 2) = make_float2(cosf(ang), sinf(ang));
+                }
             }
-        } else {                                             // Gaussian, Box-Muller (utils.py:110-117)
-            const int half = nout / 2;
-            for (int d = 0; d < half && d < 2; ++d) {
-                const float u1 = ((float)(rnd[2 * d] >> 8) + 1.0f) * (1.0f / 16777216.0f);    // (0, 1]
-                const float u2 = (float)(rnd[2 * d + 1] >> 8) * (1.0f / 16777216.0f);
+        } else {                                             // Gaussian, Box-Muller (utils.py:110-117); nout = 4:
+            const float var = quad_perm<kQuadXor2>(y[0]);    // lane d < 2 holds mu_d, lane d + 2 its variance
+            if (part < 2 && a.act) {
+                const uint32_t r0 = part == 0 ? rnd[0] : rnd[2], r1 = part == 0 ? rnd[1] : rnd[3];
+                const float u1 = ((float)(r0 >> 8) + 1.0f) * (1.0f / 16777216.0f);            // (0, 1]
+                const float u2 = (float)(r1 >> 8) * (1.0f / 16777216.0f);
                 const float n01 = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-                if (a.act) a.act[row * half + d] = fmaf(sqrtf(y[half + d]), n01, y[d]);
+                a.act[row * 2 + part] = fmaf(sqrtf(var), n01, y[0]);
             }
         }
     }
@@ -162,8 +205,9 @@ __global__ void __launch_bounds__(512) mlp3_kernel(const MArgs a)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cw = wave & 3, rh = wave >> 2;
-    const int agent = blockIdx.y;
-    const int e0 = blockIdx.x * kRows;
+    int agent, row_block;
+    xcd_work_item((a.E + kRows - 1) / kRows, agent, row_block);
+    const int e0 = row_block * kRows;
     const int ldx = a.d_in + 1, ld1 = a.h1 + 1;
     float *sx = reinterpret_cast<float *>(smem);                 // [64][d_in+1]
     float *sh1 = sx + kRows * ldx;                               // [64][h1+1]
@@ -216,24 +260,27 @@ __global__ void __launch_bounds__(512) mlp3_kernel(const MArgs a)
     for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = y[r];   // this wave's partial outputs
     __syncthreads();
 
-    // ---- output activation + sampling: one thread per env row
-    if (tid < kRows) {
-        const int e = e0 + tid;
+    // ---- output activation + sampling: four lanes per env row
+    if (tid < 4 * kRows) {
+        const int row = tid >> 2, part = tid & 3;
+        const int e = e0 + row;
         if (e >= a.E) return;
-        const int rhh = tid >> 5, rr = tid & 31;
-        float yv[kMaxOut];
-        const int nout = a.nout;
+        const int rhh = row >> 5, rr = row & 31;
+        float yv[kQ];
 #pragma unroll
-        for (int j = 0; j < kMaxOut; ++j) {
+        for (int i = 0; i < kQ; ++i) {
+            const int j = part + 4 * i;
             float v = 0.0f;
-            if (j < nout) {
+            if (j < a.nout) {
                 v = b3[j];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) v += sst[((rhh * 4 + w) * 32 + rr) * 33 + j];
             }
-            yv[j] = v;
+            yv[i] = v;
         }
-        finish_row(a.fin, yv, e, agent);
+        const uint32_t tval = (a.fin.sample_kind != 0 && a.fin.t_dev) ? (uint32_t)a.fin.t_dev[e] : 0u;
+        const uint32_t epval = (a.fin.sample_kind != 0 && a.fin.episode_dev) ? (uint32_t)a.fin.episode_dev[e] : 0u;
+        finish_quad(a.fin, yv, e, agent, part, tval, epval);
     }
 }
 
@@ -241,80 +288,41 @@ __global__ void __launch_bounds__(512) mlp3_kernel(const MArgs a)
 // bf16 variant (opt-in): weights and activations in bfloat16, float32 accumulation, on
 // v_mfma_f32_32x32x16_bf16 (16x the float32 matrix rate).  Formulated transposed -- D[feature][env row] =
 // W^T (A operand, pre-packed per fragment on the host, one 16-byte load per lane) x activations (B operand,
-// LDS, [row][k] row-major, one ds_read_b128 per lane) -- so that a lane's 4 consecutive accumulator
-// registers are 4 consecutive features of ONE env row and leave as one packed 8-byte LDS store.
+// [row][k]) -- so that a lane's accumulator registers are features of ONE env row.
 // One workgroup = 64 env rows (2 row tiles sharing every weight fragment) of one agent, 4 waves; wave w owns
-// feature chunks w, w+4, ...  63 KiB of LDS per workgroup keeps two workgroups per CU resident, so one's
-// prologue / epilogue / barriers overlap the other's MFMAs.
+// feature chunks w, w+4, ... of every layer.  <= 168 VGPRs and ~48 KiB of LDS at h = 300: three workgroups per CU.
+//   layer 1: B = x tile (LDS), relu -> h1 tile in LDS as bf16 [64][h1 pad + 8]
+//   layer 2: B = h1 tile (LDS, one ds_read_b128 per lane and fragment, fetched one k-step ahead), A = weight
+//            fragments streaming from L2 through a register ring that runs kRing k-steps ahead and across chunk
+//            borders (pinned with sched_barrier: the scheduler otherwise sinks every load next to its use).
+//            The kernel is occupancy-bound, not bandwidth-bound: at 3 workgroups per CU the MFMA pipe, the LDS
+//            and the L2 each sit near 30 %; keeping part of the h1 tile in registers (measured: up to 128 VGPRs)
+//            cut LDS traffic but cost the third workgroup and lost 20 %.
+//   layer 3: the accumulator layout of a finished layer-2 chunk (lane = env row, registers = features
+//            (r&3) + 8 (r>>2) + 4 (lane>>5)) IS a valid B operand if the k order of W3's fragments is permuted
+//            to match (done once on the host, see dronesim.h) -- bias + relu + convert in registers, no LDS.
+//   the four waves' layer-3 partials are summed through LDS, then activation + sampling, one thread per row.
 // LDS row strides are odd multiples of 16 bytes (conflict-free b128 reads).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int kRowsB = 64, kTiles = 2;        // 64 env rows (2 row tiles) per workgroup: 63 KiB of LDS, two workgroups per CU
-constexpr int kLdx = 24, kLds = 40;      // bf16 per row of the x tile / of a staged 32-feature chunk
+constexpr int kRowsB = 64, kTiles = 2;   // 64 env rows (2 row tiles) per workgroup
+constexpr int kLdx = 24;                 // bf16 per row of the x tile
+#if defined(DRONESIM_TRACE)
+long long *g_policy_trace = nullptr;     // developer builds only: [workgroups][4 waves][8] timestamps
+#define PT(k) do { if (a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PT(k) do { } while (0)
+#endif
 
 struct MArgsB {
+#if defined(DRONESIM_TRACE)
+    long long *trace;
+#endif
     int E, N, d_in, h1, h2, nc1, nc2, ks1;
     const float *x, *b1, *b2, *b3;
     const bf16x8 *w1p, *w2p, *w3p;       // [agent][chunk][k-step][64 lanes] fragments
     FinishArgs fin;
 };
-
-// acc[t] += W^T chunk (k-steps [0, ks)) x activation rows of tile t.
-// One wave per SIMD has nobody to hide latency behind, so operands are fetched one stage (2 k-steps:
-// 2 weight fragments from L2, 8 activation fragments from LDS) ahead of the 8 MFMAs that consume them,
-// ping-ponging between two register sets.
-struct StageB { bf16x8 a[2]; bf16x8 b[2][kTiles]; };
-
-__device__ __forceinline__ void load_stage(StageB &st, const bf16x8 *__restrict__ wfrag, const __bf16 *brow, int ld,
-                                           int s, int lane)
-{
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        st.a[h] = wfrag[(size_t)(s + h) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t)
-            st.b[h][t] = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + (s + h) * 16);
-    }
-}
-
-__device__ __forceinline__ void mma_stage(f32x16 (&acc)[kTiles], const StageB &st)
-{
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(st.a[h], st.b[h][t], acc[t], 0, 0, 0);
-}
-
-__device__ __forceinline__ void chunk_gemm(f32x16 (&acc)[kTiles], const bf16x8 *__restrict__ wfrag, int ks,
-                                           const __bf16 *act, int ld, int lane)
-{
-    const __bf16 *brow = act + (lane & 31) * ld + 8 * (lane >> 5);
-    const int kse = ks & ~1;                               // whole stages
-    if (kse > 0) {
-        StageB p, q;
-        load_stage(p, wfrag, brow, ld, 0, lane);
-        int s = 0;
-        while (true) {
-            if (s + 2 < kse) load_stage(q, wfrag, brow, ld, s + 2, lane);
-            mma_stage(acc, p);
-            s += 2;
-            if (s >= kse) break;
-            if (s + 2 < kse) load_stage(p, wfrag, brow, ld, s + 2, lane);
-            mma_stage(acc, q);
-            s += 2;
-            if (s >= kse) break;
-        }
-    }
-    if (ks & 1) {                                          // odd tail (layer 1: a single k-step)
-        const bf16x8 a0 = wfrag[(size_t)kse * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < kTiles; ++t) {
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld + kse * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[t], 0, 0, 0);
-        }
-    }
-}
 
 // relu(acc + bias) of one 32-feature chunk -> bf16 rows [row][feature].  `bias` points at the chunk's 32 biases
 // in LDS (zero beyond the layer width; the padded weights are zero there too, so those features come out 0).
@@ -336,56 +344,156 @@ __device__ __forceinline__ void store_chunk(const f32x16 (&acc)[kTiles], const f
     }
 }
 
-__global__ void __launch_bounds__(256, 2) mlp3_bf16_kernel(const MArgsB a)
+template <int NC1>                       // 32-feature chunks of the first hidden layer (h1 <= 32 NC1)
+__global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const MArgsB a)
 {
+    // occupancy first: h1 <= 256 leaves LDS for four workgroups per CU, which needs <= 128 VGPRs (ring of 4);
+    // wider layers fit three (two beyond h1 = 352), where 168 VGPRs allow weight fragments 8 k-steps ahead
+    constexpr int kRing = NC1 <= 8 ? 4 : 8;
+    constexpr int KS2 = 2 * NC1;                         // k-steps (of 16) of layer 2
+    constexpr int L1C = (NC1 + 3) / 4;                   // layer-1 chunks per wave (upper bound)
+    constexpr int kMaxChunks = 4;                        // layer-2 chunks per wave: h2 <= 512
+    constexpr int ld1 = NC1 * 32 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int agent = blockIdx.y;
-    const int e0 = blockIdx.x * kRowsB;
-    const int ld1 = a.nc1 * 32 + 8;
+    int agent, row_block;
+    xcd_work_item((a.E + kRowsB - 1) / kRowsB, agent, row_block);
+    const int e0 = row_block * kRowsB;
+    const int nb = (NC1 + a.nc2) * 32;
     __bf16 *sx = reinterpret_cast<__bf16 *>(smem);                 // [64][24]
-    __bf16 *sst = sx + kRowsB * kLdx;                              // [4 waves][64][40]
-    float *sbias = reinterpret_cast<float *>(sst + 4 * kRowsB * kLds);   // [nc1*32 + nc2*32] zero-padded biases
-    __bf16 *sh1 = reinterpret_cast<__bf16 *>(sbias + (a.nc1 + a.nc2) * 32);   // [64][ld1]; later f32 partials [4][64][33]
+    float *sbias = reinterpret_cast<float *>(sx + kRowsB * kLdx);  // b1 | b2 (zero padded to chunks) | b3 (32)
+    __bf16 *sh1 = reinterpret_cast<__bf16 *>(sbias + nb + 32);     // [64][ld1]; later f32 partials [4][64][33]
     float *spart = reinterpret_cast<float *>(sh1);
+    PT(0);
 
-    for (int idx = tid; idx < kRowsB * 16; idx += 256) {           // x tile, zero padded to k = 16
-        const int r = idx >> 4, c = idx & 15;
-        const int e = e0 + r;
-        const float v = (c < a.d_in && e < a.E) ? a.x[((size_t)e * a.N + agent) * a.d_in + c] : 0.0f;
-        sx[r * kLdx + c] = (__bf16)v;
+    // ---- everything that does not depend on LDS is requested up front: x, biases, the sampling counters of
+    //      this thread's row, this wave's layer-1 fragments and the head of its layer-2 weight stream
+    float xv[4];                                                   // x tile: thread = (row, 4 of 16 k slots)
+    {
+        const int r = tid >> 2, c0 = (tid & 3) * 4, e = e0 + r;
+        const float *xr = a.x + ((size_t)e * a.N + agent) * a.d_in;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = (e < a.E && c0 + j < a.d_in) ? xr[c0 + j] : 0.0f;   // zero padded to k = 16
     }
-    for (int idx = tid; idx < (a.nc1 + a.nc2) * 32; idx += 256) {  // biases once, so no epilogue waits on L2
-        const int f = idx < a.nc1 * 32 ? idx : idx - a.nc1 * 32;
-        sbias[idx] = idx < a.nc1 * 32 ? (f < a.h1 ? a.b1[(size_t)agent * a.h1 + f] : 0.0f)
-                                      : (f < a.h2 ? a.b2[(size_t)agent * a.h2 + f] : 0.0f);
+    uint32_t tval = 0, epval = 0;
+    if (e0 + (tid >> 2) < a.E && a.fin.sample_kind != 0) {          // of the row this thread finishes (4 lanes per row)
+        if (a.fin.t_dev) tval = (uint32_t)a.fin.t_dev[e0 + (tid >> 2)];
+        if (a.fin.episode_dev) epval = (uint32_t)a.fin.episode_dev[e0 + (tid >> 2)];
     }
+    float bv[5];                                                   // (16 + 16) * 32 + 32 <= 5 * 256 bias words
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+        const int idx = tid + 256 * u;
+        float v = 0.0f;
+        if (idx < NC1 * 32) { if (idx < a.h1) v = a.b1[(size_t)agent * a.h1 + idx]; }
+        else if (idx < nb) { if (idx - NC1 * 32 < a.h2) v = a.b2[(size_t)agent * a.h2 + idx - NC1 * 32]; }
+        else if (idx - nb < a.fin.nout) v = a.b3[(size_t)agent * a.fin.nout + idx - nb];
+        bv[u] = v;
+    }
+    bf16x8 w1f[L1C];
+#pragma unroll
+    for (int i = 0; i < L1C; ++i)
+        if (wave + 4 * i < NC1) w1f[i] = a.w1p[((size_t)agent * NC1 + wave + 4 * i) * 64 + lane];
+    const bf16x8 *w2a = a.w2p + (size_t)agent * a.nc2 * KS2 * 64 + lane;
+    const bf16x8 *w3a = a.w3p + (size_t)agent * a.nc2 * 2 * 64 + lane;
+    bf16x8 ring[kRing];
+#pragma unroll
+    for (int g = 0; g < kRing; ++g) {                              // stream position g = chunk slot * KS2 + k-step
+        const int c = wave + 4 * (g / KS2);
+        if (g / KS2 < kMaxChunks && c < a.nc2) ring[g] = w2a[((size_t)c * KS2 + g % KS2) * 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);                             // all requests are out before anything waits
+    {
+        bf16x4 p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[j] = (__bf16)xv[j];
+        *reinterpret_cast<bf16x4 *>(sx + (tid >> 2) * kLdx + (tid & 3) * 4) = p;
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+        if (tid + 256 * u < nb + 32) sbias[tid + 256 * u] = bv[u];
     __syncthreads();
+    PT(1);
 
     // ---- layer 1 -> sh1 (bf16): wave w owns feature chunks w, w+4, ...
-    for (int c = wave; c < a.nc1; c += 4) {
-        f32x16 acc[kTiles] = {};
-        chunk_gemm(acc, a.w1p + ((size_t)agent * a.nc1 + c) * a.ks1 * 64, a.ks1, sx, kLdx, lane);
-        store_chunk(acc, sbias + c * 32, sh1 + c * 32, ld1, lane);
+    {
+        const __bf16 *xrow = sx + (lane & 31) * kLdx + 8 * (lane >> 5);
+        bf16x8 bx[kTiles];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) bx[t] = *reinterpret_cast<const bf16x8 *>(xrow + t * 32 * kLdx);
+#pragma unroll
+        for (int i = 0; i < L1C; ++i) {
+            const int c = wave + 4 * i;
+            if (c < NC1) {
+                f32x16 acc[kTiles] = {};
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1f[i], bx[t], acc[t], 0, 0, 0);
+                store_chunk(acc, sbias + c * 32, sh1 + c * 32, ld1, lane);
+            }
+        }
     }
+    PT(2);
     __syncthreads();
+    PT(3);
 
     // ---- layers 2 + 3 fused over this wave's feature chunks
+    const __bf16 *brow = sh1 + (lane & 31) * ld1 + 8 * (lane >> 5);
     f32x16 y[kTiles] = {};
-    __bf16 *st = sst + wave * kRowsB * kLds;
-    const int ks2 = a.nc1 * 2;
-    for (int c = wave; c < a.nc2; c += 4) {
-        f32x16 acc[kTiles] = {};
-        chunk_gemm(acc, a.w2p + ((size_t)agent * a.nc2 + c) * ks2 * 64, ks2, sh1, ld1, lane);
-        store_chunk(acc, sbias + (a.nc1 + c) * 32, st, kLds, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        chunk_gemm(y, a.w3p + ((size_t)agent * a.nc2 * 2 + 2 * c) * 64, 2, st, kLds, lane);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    PT(4);
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = wave + 4 * i;
+        if (c < a.nc2) {                                           // wave-uniform
+            bf16x8 w3f[2];
+            w3f[0] = w3a[(size_t)(2 * c) * 64];
+            w3f[1] = w3a[(size_t)(2 * c + 1) * 64];
+            f32x16 acc[kTiles] = {};
+            bf16x8 bl[2][kTiles];                                   // h1 fragments, fetched one k-step ahead
+#pragma unroll
+            for (int t = 0; t < kTiles; ++t) bl[0][t] = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld1);
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const int g = i * KS2 + s;
+                if (s + 1 < KS2) {
+#pragma unroll
+                    for (int t = 0; t < kTiles; ++t)
+                        bl[(s + 1) & 1][t] = *reinterpret_cast<const bf16x8 *>(brow + t * 32 * ld1 + (s + 1) * 16);
+                }
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[g % kRing], bl[s & 1][t], acc[t], 0, 0, 0);
+                const int g2 = g + kRing, i2 = g2 / KS2;           // refill the slot just consumed
+                if (i2 < kMaxChunks) {
+                    const int c2 = wave + 4 * i2;
+                    if (c2 < a.nc2) ring[g % kRing] = w2a[((size_t)c2 * KS2 + g2 % KS2) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);                 // keep the ring kRing steps ahead: the scheduler
+            }                                                      // otherwise sinks each load next to its use
+            // bias + relu in registers; registers 8 s .. 8 s + 7 of a lane are the k slots of layer-3 k-step s
+            const float *bc = sbias + (NC1 + c) * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(bc + 16 * s);
+                const float4 b1 = *reinterpret_cast<const float4 *>(bc + 16 * s + 8);
+#pragma unroll
+                for (int t = 0; t < kTiles; ++t) {
+                    bf16x8 p;
+                    p[0] = (__bf16)fmaxf(acc[t][8 * s + 0] + b0.x, 0.0f);
+                    p[1] = (__bf16)fmaxf(acc[t][8 * s + 1] + b0.y, 0.0f);
+                    p[2] = (__bf16)fmaxf(acc[t][8 * s + 2] + b0.z, 0.0f);
+                    p[3] = (__bf16)fmaxf(acc[t][8 * s + 3] + b0.w, 0.0f);
+                    p[4] = (__bf16)fmaxf(acc[t][8 * s + 4] + b1.x, 0.0f);
+                    p[5] = (__bf16)fmaxf(acc[t][8 * s + 5] + b1.y, 0.0f);
+                    p[6] = (__bf16)fmaxf(acc[t][8 * s + 6] + b1.z, 0.0f);
+                    p[7] = (__bf16)fmaxf(acc[t][8 * s + 7] + b1.w, 0.0f);
+                    y[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3f[s], p, y[t], 0, 0, 0);
+                }
+            }
+        }
     }
+    PT(5);
     __syncthreads();                                               // everyone is done reading sh1
 #pragma unroll
     for (int t = 0; t < kTiles; ++t)
@@ -393,24 +501,41 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16_kernel(const MArgsB a)
         for (int r = 0; r < 16; ++r)
             spart[((size_t)wave * kRowsB + t * 32 + (lane & 31)) * 33 + cd_row(r, lane)] = y[t][r];
     __syncthreads();
+    PT(6);
 
-    if (tid < kRowsB) {
-        const int e = e0 + tid;
+    {
+        const int row = tid >> 2, part = tid & 3;
+        const int e = e0 + row;
         if (e >= a.E) return;
-        const float *b3 = a.b3 + (size_t)agent * a.fin.nout;
-        float yv[kMaxOut];
+        float yv[kQ];
 #pragma unroll
-        for (int j = 0; j < kMaxOut; ++j) {
+        for (int i = 0; i < kQ; ++i) {
+            const int j = part + 4 * i;
             float v = 0.0f;
             if (j < a.fin.nout) {
-                v = b3[j];
+                v = sbias[nb + j];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += spart[((size_t)w * kRowsB + tid) * 33 + j];
+                for (int w = 0; w < 4; ++w) v += spart[((size_t)w * kRowsB + row) * 33 + j];
             }
-            yv[j] = v;
+            yv[i] = v;
         }
-        finish_row(a.fin, yv, e, agent);
+        finish_quad(a.fin, yv, e, agent, part, tval, epval);
+        PT(7);
     }
+}
+
+template <int NC1>
+int launch_bf16(const MArgsB &a, size_t lds, hipStream_t stream)
+{
+    static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
+    if (lds > 48 * 1024 && !big_lds_enabled) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_bf16_kernel<NC1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return dronesim_fail(DRONESIM_ELAUNCH, "cannot enable 160 KiB of dynamic LDS for mlp3_bf16_kernel");
+        big_lds_enabled = true;
+    }
+    hipLaunchKernelGGL(mlp3_bf16_kernel<NC1>, dim3(((a.E + kRowsB - 1) / kRowsB) * a.N), dim3(256), lds, stream, a);
+    return DRONESIM_OK;
 }
 
 FinishArgs make_finish(int N, int nout, int out_kind, int sample_kind, float *out, float *act, int32_t *act_idx,
@@ -440,6 +565,10 @@ int check_mlp(const char *who, int N, int d_in, int h1, int h2, int nout, int ou
 
 }   // namespace
 
+#if defined(DRONESIM_TRACE)
+extern "C" void dronesim_debug_set_policy_trace(long long *p) { g_policy_trace = p; }
+#endif
+
 extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                                          uint64_t seed, uint64_t counter, int64_t env_base,
                                          const int32_t *t, const int32_t *episode, int E, void *stream)
@@ -452,6 +581,9 @@ extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, 
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16: NULL weight array");
     if (E == 0) return DRONESIM_OK;
     MArgsB a{};
+#if defined(DRONESIM_TRACE)
+    a.trace = g_policy_trace;
+#endif
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2;
     a.nc1 = (m->h1 + 31) / 32; a.nc2 = (m->h2 + 31) / 32; a.ks1 = 1;
     a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
@@ -460,17 +592,21 @@ extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, 
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
     const size_t sh1_bytes = sizeof(__bf16) * kRowsB * ((size_t)a.nc1 * 32 + 8);
     const size_t part_bytes = sizeof(float) * 4 * kRowsB * 33;
-    const size_t lds = sizeof(__bf16) * (kRowsB * kLdx + 4 * kRowsB * kLds) + sizeof(float) * 32 * (a.nc1 + a.nc2) +
+    const size_t lds = sizeof(__bf16) * kRowsB * kLdx + sizeof(float) * (32 * (a.nc1 + a.nc2) + 32) +
                        (sh1_bytes > part_bytes ? sh1_bytes : part_bytes);
-    static bool big_lds_enabled = false;
-    if (!big_lds_enabled) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return dronesim_fail(DRONESIM_ELAUNCH, "cannot enable 160 KiB of dynamic LDS for mlp3_bf16_kernel");
-        big_lds_enabled = true;
-    }
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
-    hipLaunchKernelGGL(mlp3_bf16_kernel, dim3((E + kRowsB - 1) / kRowsB, m->N), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int lrc = DRONESIM_OK;
+    switch (a.nc1) {                                     // the h1 tile's register residency is compile-time
+#define DRONESIM_BF16_CASE(n) case n: lrc = launch_bf16<n>(a, lds, s); break;
+        DRONESIM_BF16_CASE(1) DRONESIM_BF16_CASE(2) DRONESIM_BF16_CASE(3) DRONESIM_BF16_CASE(4)
+        DRONESIM_BF16_CASE(5) DRONESIM_BF16_CASE(6) DRONESIM_BF16_CASE(7) DRONESIM_BF16_CASE(8)
+        DRONESIM_BF16_CASE(9) DRONESIM_BF16_CASE(10) DRONESIM_BF16_CASE(11) DRONESIM_BF16_CASE(12)
+        DRONESIM_BF16_CASE(13) DRONESIM_BF16_CASE(14) DRONESIM_BF16_CASE(15) DRONESIM_BF16_CASE(16)
+#undef DRONESIM_BF16_CASE
+        default: return dronesim_fail(DRONESIM_EUNSUPPORTED, "bf16 path: h1 <= 512");
+    }
+    if (lrc) return lrc;
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
@@ -499,7 +635,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
         big_lds_enabled = true;
     }
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
-    hipLaunchKernelGGL(mlp3_kernel, dim3((E + kRows - 1) / kRows, m->N), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(mlp3_kernel, dim3(((E + kRows - 1) / kRows) * m->N), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

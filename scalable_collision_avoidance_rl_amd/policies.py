@@ -26,15 +26,24 @@ def _wt(layer):
     return layer.weight.detach().t().contiguous().float(), layer.bias.detach().contiguous().float()
 
 
-def pack_bf16_fragments(w, ksteps, nchunks):
-    """[N, K, F] float weights -> matrix-core fragments [N, nchunks, ksteps, 64, 8] in bf16
-    (frag[a, c, s, l, j] = w[a, 16 s + 8 (l >> 5) + j, 32 c + (l & 31)], zero beyond K / F) --
-    the layout `dronesim_mlp_forward_bf16` reads with one 16-byte load per lane."""
+def pack_bf16_fragments(w, ksteps, nchunks, k_order="linear"):
+    """[N, K, F] float weights -> matrix-core fragments [N, nchunks, ksteps, 64, 8] in bf16, the layout
+    `dronesim_mlp_forward_bf16` reads with one 16-byte load per lane:
+        frag[a, c, s, l, j] = w[a, kmap(s, l >> 5, j), 32 c + (l & 31)]      (zero beyond K / F)
+    k_order "linear" (layers 1, 2): kmap = 16 s + 8 h + j.
+    k_order "accumulator" (layer 3): kmap = 16 s + 8 (j >> 2) + 4 h + (j & 3) -- the order in which a lane of
+    the previous layer's accumulator tile holds its features, so that tile feeds layer 3 from registers."""
     import torch
     n, k, f = w.shape
     pad = torch.zeros(n, ksteps * 16, nchunks * 32, dtype=torch.float32, device=w.device)
     pad[:, :k, :f] = w
-    frag = pad.view(n, ksteps, 2, 8, nchunks, 32).permute(0, 4, 1, 2, 5, 3)      # [N, c, s, h, i, j]
+    if k_order == "linear":
+        frag = pad.view(n, ksteps, 2, 8, nchunks, 32).permute(0, 4, 1, 2, 5, 3)           # [N, c, s, h, i, j]
+    elif k_order == "accumulator":
+        # k = 16 s + 8 jh + 4 h + jl  -> axes (s, jh, h, jl); wanted [N, c, s, h, i, (jh, jl)]
+        frag = pad.view(n, ksteps, 2, 2, 4, nchunks, 32).permute(0, 5, 1, 3, 6, 2, 4)
+    else:
+        raise ValueError("k_order must be 'linear' or 'accumulator'")
     return frag.reshape(n, nchunks, ksteps, 64, 8).to(torch.bfloat16).contiguous()
 
 
@@ -70,7 +79,7 @@ class BatchedMLP:
             nc1, nc2 = (self.h1 + 31) // 32, (self.h2 + 31) // 32
             self._w1p = pack_bf16_fragments(self.w1, 1, nc1)
             self._w2p = pack_bf16_fragments(self.w2, 2 * nc1, nc2)
-            self._w3p = pack_bf16_fragments(self.w3, 2 * nc2, 1)
+            self._w3p = pack_bf16_fragments(self.w3, 2 * nc2, 1, k_order="accumulator")
             mb = _native.DroneMlpBf16()
             mb.N, mb.d_in, mb.h1, mb.h2, mb.nout = self.n_agents, self.d_in, self.h1, self.h2, self.nout
             mb.out_kind, mb.sample_kind = self.out_kind, self.sample_kind

@@ -109,3 +109,22 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "libdrone_oracle" not in src, f
+
+
+def test_bf16_fragment_packing_layouts():
+    """pack_bf16_fragments against the index formulas of include/dronesim.h (both k orders), on CPU tensors."""
+    import torch
+    from scalable_collision_avoidance_rl_amd.policies import pack_bf16_fragments
+    g = torch.Generator().manual_seed(0)
+    n, k, f, ks, nc = 2, 40, 50, 3, 2                      # ragged: K = 40 < 48, F = 50 < 64
+    w = torch.randint(-100, 100, (n, k, f), generator=g).float()       # exactly representable in bf16
+    for order, kmap in (("linear", lambda s, h, j: 16 * s + 8 * h + j),
+                        ("accumulator", lambda s, h, j: 16 * s + 8 * (j >> 2) + 4 * h + (j & 3))):
+        frag = pack_bf16_fragments(w, ks, nc, k_order=order).float().numpy()
+        assert frag.shape == (n, nc, ks, 64, 8)
+        for a, c, s, l, j in [(0, 0, 0, 0, 0), (1, 1, 2, 63, 7), (0, 1, 1, 37, 5), (1, 0, 2, 31, 6), (0, 1, 2, 40, 3)]:
+            kk, ff = kmap(s, l >> 5, j), 32 * c + (l & 31)
+            want = float(w[a, kk, ff]) if kk < k and ff < f else 0.0
+            assert frag[a, c, s, l, j] == want, (order, a, c, s, l, j)
+        # every weight appears exactly once
+        assert np.isclose(np.abs(frag).sum(), float(w.abs().sum()))
