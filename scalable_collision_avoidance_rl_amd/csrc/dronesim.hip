@@ -47,6 +47,10 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kChunk = 16;         // partners whose LDS reads are in flight together (pass 1)
 constexpr int kPad = kChunk + 4;   // LDS slack so the last chunk may over-read (+ the shifted copy's offset)
+constexpr int kCells = 64;          // cells per axis of the bucket filter (coordinates are hashed: cell & 63)
+constexpr int kBucketRows = 66;     // cells 0..63 plus one empty guard row at either end
+constexpr int kBucketMinN = 40;     // packed envs smaller than this scan all partners (the tables would cost more)
+constexpr int kBucketMax = 10;      // candidates per agent beyond which the all-pairs scan is cheaper
 constexpr float kLn2 = 0.693147180559945309f;
 
 enum Mode { kStep = 0, kObserve = 1, kRollout = 2 };
@@ -71,6 +75,7 @@ struct KArgs {
     uint8_t *done;
     const uint8_t *mask;
     float skin;                     // rollout, kSym64: slack radius of the register-resident candidate list
+    int bucket;                     // packed geometry: use the bucket far filter (N >= 24)
     int uniform;                    // all agents share d_hat, Delta and radius (host-known): constants come
     float dhat_u, delta_u, radius_u;   //   from the kernel arguments, no per-agent table is read
 };
@@ -168,7 +173,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 {
     constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
     constexpr bool SYM = GEO == kSym64;
-    constexpr bool SYMB = (GEO == kBlock256 || GEO == kBlock1024) && !FAR;   // pair-once scan for N > 64
+    // generic bucket filter (see below): always for N > 64, for packed envs when the host asks for it (N >= 24)
+    constexpr bool BLOCKGEO = GEO == kBlock256 || GEO == kBlock1024;
+    constexpr int WMAX = GEO == kBlock1024 ? 16 : GEO == kBlock256 ? 4 : 1;   // 64-agent words per env
     static_assert(!(SYM && FAR), "the symmetric filter assumes far agents never matter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TRACE_MARK(0);
@@ -249,9 +256,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     unsigned *stage_z = sstage + (size_t)wave * kWave * (kZRow + kNRow);                   // [64][kZRow]
     unsigned *stage_n = stage_z + kWave * kZRow;                                           // [64][kNRow]
     float2 *sconst = sconst_all + (WL ? (size_t)wave * (N + (N & 1)) : 0);
-    // SYMB: per agent, one bit per backward offset r = 1..N/2 set by the partner that scanned the pair
-    const int nbw = (N / 2 + 31) >> 5;
-    unsigned *sback = sstage + (size_t)nwaves * kWave * (kZRow + kNRow);                   // [N][nbw]
+    // bucket filter tables.  kSym64: per wave, cell -> lane mask, entries -1..64 of (x mask, y mask).
+    // Other geometries: per env slot, [axis][W words of 64 agents][64 cells].
+    unsigned long long *sbt_all = reinterpret_cast<unsigned long long *>(sstage + (size_t)nwaves * kWave * (kZRow + kNRow));
+    ulonglong2 *sbucket = reinterpret_cast<ulonglong2 *>(sbt_all) + (size_t)wave * kBucketRows + 1;
+    const int W = BLOCKGEO ? nwaves : 1;
+    const bool use_bucket = !FAR && !SYM && (BLOCKGEO || a.bucket != 0);                   // launch-uniform
+    unsigned long long *sbt = sbt_all + (size_t)slot * (2 * kCells) * W;                   // this lane's env
 
     // (Delta_j, l_j) of a partner: kernel-argument scalars when all agents share them -- except in the fused
     // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
@@ -265,10 +276,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         if (!uni_args)
             for (int s = tid; s < N; s += blockDim.x)
                 sconst[s] = a.uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[s], a.radius[s]);
-        if (SYMB) for (int s = tid; s < N * nbw; s += blockDim.x) sback[s] = 0u;
     }
 
-    const float reach = (SYM || SYMB) ? a.reach_max : dhat + li + a.radius_max;
+    const float reach = SYM ? a.reach_max : dhat + li + a.radius_max;
     const float thr = reach * reach * 1.000001f;             // early-out radius^2 (conservative)
     const float log2_dhat = __builtin_amdgcn_logf(dhat);     // v_log_f32 = log2
     float2 *spos_env = spos + (size_t)slot * 2 * stride;     // S0 of this lane's env
@@ -285,6 +295,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     constexpr bool CACHED = SYM && MODE == kRollout;
     const float thr_list = CACHED ? (reach + a.skin) * (reach + a.skin) * 1.000001f : thr;
     const float moved2 = 0.49f * a.skin * 0.49f * a.skin;
+    const float inv_cell = __builtin_amdgcn_rcpf((CACHED ? reach + a.skin : a.reach_max) * 1.001f);   // bucket filter: cells a little wider than the list radius
     unsigned long long cand = 0ull;
     float refx = __builtin_nanf(""), refy = refx;            // NaN = no list yet
 
@@ -301,13 +312,32 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 vxi = u.x; vyi = u.y;                         // drone_env.py:238
             }
             spos_env[agent] = make_float2(xi, yi);
-            spos_env[agent + N] = make_float2(xi, yi);
-            spos_env[stride + agent + 1] = make_float2(xi, yi);
-            spos_env[stride + agent + N + 1] = make_float2(xi, yi);
+            if (!use_bucket) {                                // relative partner windows (dup index agent + r)
+                spos_env[agent + N] = make_float2(xi, yi);
+                if (!FAR) {
+                    spos_env[stride + agent + 1] = make_float2(xi, yi);
+                    spos_env[stride + agent + N + 1] = make_float2(xi, yi);
+                }
+            }
+        }
+        // ---- generic bucket filter, part 1: every agent ORs its bit into the mask of its x cell and of its y cell
+        int bcx = 0, bcy = 0;
+        if (use_bucket) {
+            if (WL) { for (int o = lane; o < a.P * 2 * kCells; o += kWave) sbt_all[(size_t)wave * a.P * 2 * kCells + o] = 0ull; }
+            else { for (int o = tid; o < 2 * kCells * W; o += blockDim.x) sbt_all[o] = 0ull; }
+            bcx = (int)__builtin_floorf(xi * inv_cell) & (kCells - 1);
+            bcy = (int)__builtin_floorf(yi * inv_cell) & (kCells - 1);
         }
         TRACE_MARK(1);
         group_sync<WL>();
         TRACE_MARK(2);
+        if (use_bucket) {
+            if (valid) {
+                atomicOr(&sbt[(agent >> 6) * kCells + bcx], 1ull << (agent & 63));           // [axis][word][cell]:
+                atomicOr(&sbt[(W + (agent >> 6)) * kCells + bcy], 1ull << (agent & 63));     // lanes spread over banks
+            }
+            group_sync<WL>();
+        }
 
         float zrx[K + 1], zry[K + 1];
         int nbv[K + 1];
@@ -343,10 +373,78 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             nbr_insert<K>(list, nbr_key(d, j));                               // :338
         };
 
-        if (valid) {
-            // partners to scan "forward": all N-1 of them, or (symmetric variants) only the nearer half --
-            // the other end of each pair then gets the verdict through a ballot (kSym64) or an LDS bit (SYMB)
-            const int rmax = SYMB ? N / 2 : N - 1;
+        if (valid && use_bucket) {
+            // ---- generic bucket filter, part 2.  Cells are at least reach_max wide, so every partner inside this
+            // agent's radius sits in its cell or a neighbouring one on BOTH axes (cell numbers are hashed mod 64:
+            // far-away cells alias, which only adds candidates).  candidates = (3 x masks) & (3 y masks), exact
+            // test per candidate, then pass 2 in ascending agent order.  A wave that finds one of its agents
+            // crowded tests all partners instead (broadcast reads, same order, same verdicts).
+            unsigned long long pool[WMAX];
+            int npool = 0;
+            const int cxm = (bcx - 1) & (kCells - 1), cxp = (bcx + 1) & (kCells - 1);
+            const int cym = (bcy - 1) & (kCells - 1), cyp = (bcy + 1) & (kCells - 1);
+#pragma unroll
+            for (int w = 0; w < WMAX; ++w) {
+                pool[w] = 0ull;
+                if (w < W) {
+                    const unsigned long long *tx = sbt + w * kCells, *ty = sbt + (W + w) * kCells;
+                    unsigned long long m = (tx[cxm] | tx[bcx] | tx[cxp]) & (ty[cym] | ty[bcy] | ty[cyp]);
+                    if (w == (agent >> 6)) m &= ~(1ull << (agent & 63));
+                    pool[w] = m;
+                    npool += __builtin_popcountll(m);
+                }
+            }
+            const bool crowded = __builtin_amdgcn_ballot_w64(npool > kBucketMax) != 0ull;
+#pragma unroll
+            for (int w = 0; w < WMAX; ++w) {
+                if (w < W) {
+                    unsigned long long hits = 0ull;
+#if defined(DRONESIM_ABLATE_PASS1)
+                    if (true) { hits = (xi == 123.456f) ? 1ull : 0ull; } else
+#endif
+                    if (crowded) {
+                        const int jn = min(64, N - 64 * w);
+#pragma unroll
+                        for (int c4 = 0; c4 < 4; ++c4) {
+                            const int cnt = jn - c4 * kChunk;
+                            if (cnt > 0) {
+                                const float4 *pp = reinterpret_cast<const float4 *>(spos_env + 64 * w + c4 * kChunk);
+                                unsigned m = 0u;
+#pragma unroll
+                                for (int u = 0; u < kChunk / 2; ++u) {
+                                    const float4 v = pp[u];
+                                    const float dx0 = xi - v.x, dy0 = yi - v.y, dx1 = xi - v.z, dy1 = yi - v.w;
+                                    m |= (fmaf(dy0, dy0, dx0 * dx0) < thr ? 1u : 0u) << (2 * u);
+                                    m |= (fmaf(dy1, dy1, dx1 * dx1) < thr ? 1u : 0u) << (2 * u + 1);
+                                }
+                                if (cnt < kChunk) m &= (1u << cnt) - 1u;
+                                hits |= (unsigned long long)m << (c4 * kChunk);
+                            }
+                        }
+                        if (w == (agent >> 6)) hits &= ~(1ull << (agent & 63));
+                    } else if (__builtin_amdgcn_ballot_w64(pool[w] != 0ull) != 0ull) {
+                        unsigned long long m = pool[w];
+                        while (m) {
+                            const int u = __builtin_ctzll(m);
+                            m &= m - 1ull;
+                            const float2 pj = spos_env[64 * w + u];
+                            const float dx = xi - pj.x, dy = yi - pj.y;
+                            if (fmaf(dy, dy, dx * dx) < thr) hits |= 1ull << u;
+                        }
+                    }
+#if defined(DRONESIM_ABLATE_PASS2)
+                    s_all += (float)__builtin_popcountll(hits); hits = 0ull;
+#endif
+                    while (hits) {
+                        const int u = __builtin_ctzll(hits);
+                        hits &= hits - 1ull;
+                        visit(64 * w + u);
+                    }
+                }
+            }
+        }
+        if (valid && !use_bucket) {
+            const int rmax = N - 1;
             for (int r0 = 1; r0 <= rmax; r0 += 64) {
                 // ---- pass 1: far filter, 16 partners in flight.  Result: one bit per partner to revisit.
                 unsigned long long near = 0ull;
@@ -365,6 +463,36 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         near = cand;
                     }
                     if (rebuild) {
+                    // (a) bucket filter: cells of width >= the list radius along x and along y; a partner can
+                    //     only be inside the radius if it sits in this agent's cell or a neighbouring one on
+                    //     BOTH axes.  Each lane ORs its lane bit into the mask of its x cell and of its y cell
+                    //     (LDS atomics), then reads the three masks around its own cell per axis:
+                    //     candidates = (x masks) & (y masks).  Coordinates beyond the 64 cells clamp to the end
+                    //     cells, which only ever adds candidates.  ~35 instructions instead of 32 offsets x 5+.
+                    const unsigned long long self = 1ull << lane;
+                    sbucket[(int)lane] = make_ulonglong2(0ull, 0ull);
+                    if (lane < 2) sbucket[lane == 0 ? -1 : 64] = make_ulonglong2(0ull, 0ull);
+                    const int cx = (int)fminf(fmaxf(xi * inv_cell, 0.0f), 63.0f);
+                    const int cy = (int)fminf(fmaxf(yi * inv_cell, 0.0f), 63.0f);
+                    group_sync<true>();
+                    atomicOr(&sbucket[cx].x, self);
+                    atomicOr(&sbucket[cy].y, self);
+                    group_sync<true>();
+                    unsigned long long pool = (sbucket[cx - 1].x | sbucket[cx].x | sbucket[cx + 1].x) &
+                                              (sbucket[cy - 1].y | sbucket[cy].y | sbucket[cy + 1].y) & ~self;
+                    unsigned long long hits = 0ull;          // bit j: agent j is inside the list radius
+                    if (__builtin_amdgcn_ballot_w64(__builtin_popcountll(pool) > kBucketMax) == 0ull) {
+                        // (b) exact test of the few candidates
+                        while (pool) {
+                            const int j = __builtin_ctzll(pool);
+                            pool &= pool - 1ull;
+                            const float2 pj = spos_env[j];
+                            const float dx = xi - pj.x, dy = yi - pj.y;
+                            if (fmaf(dy, dy, dx * dx) < thr_list) hits |= 1ull << j;
+                        }
+                    } else {
+                    // (c) crowded env: every unordered pair once -- lane i tests partners i+1..i+32 and the
+                    //     verdict reaches the other end as a rotated ballot
                     unsigned mf = 0u, mb = 0u;
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
@@ -382,7 +510,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                             const float d2 = fmaf(dy, dy, dx * dx);
                             const bool f = d2 < thr_list;
                             const unsigned long long fm = __builtin_amdgcn_ballot_w64(f);
-                            if (fm) {                                         // wave-uniform: ~2/3 of the offsets have no hit
+                            if (fm) {                                         // wave-uniform
                                 mf |= (f ? 1u : 0u) << (r - 1);
                                 if (r < 32) {                                 // r = 32: both ends see it as forward
                                     const unsigned long long bm = (fm << r) | (fm >> (64 - r));   // lane i -> lane i+r
@@ -391,7 +519,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                             }
                         }
                     }
-                    near = (unsigned long long)mf | ((unsigned long long)mb << 32);
+                    // offsets -> agent indices: forward bit u is agent i+1+u, backward bit u is agent i-1-u
+                    const unsigned long long fw = (unsigned long long)mf, bw = (unsigned long long)__builtin_bitreverse32(mb);
+                    const unsigned sf = (lane + 1) & 63u, sb = (lane + 32) & 63u;
+                    hits = ((fw << sf) | (sf ? fw >> (64 - sf) : 0ull)) | ((bw << sb) | (sb ? bw >> (64 - sb) : 0ull));
+                    }
+                    near = hits;
                     if (CACHED) { cand = near; refx = xi; refy = yi; }
                     }
                 } else {
@@ -414,17 +547,6 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                                 m |= (d2 < thr ? 1u : 0u) << u;
                             }
                             if (cnt < kChunk) m &= (1u << cnt) - 1u;
-                            if (SYMB && __builtin_amdgcn_ballot_w64(m != 0u)) {   // rare: tell the other end of each hit
-                                unsigned mm = m;
-                                while (mm) {
-                                    const int r = r0 + c4 * kChunk + __builtin_ctz(mm);
-                                    mm &= mm - 1u;
-                                    if (2 * r != N) {                        // r = N/2: the partner scans this pair itself
-                                        int j = agent + r; j -= (j >= N) ? N : 0;
-                                        atomicOr(&sback[j * nbw + ((r - 1) >> 5)], 1u << ((r - 1) & 31));
-                                    }
-                                }
-                            }
                             near |= (unsigned long long)m << (c4 * kChunk);
                         }
                     }
@@ -436,22 +558,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 while (near) {
                     const int u = __builtin_ctzll(near);
                     near &= near - 1ull;
-                    visit(SYM ? (u < 32 ? agent + 1 + u : agent + 95 - u) : agent + r0 + u);
-                }
-            }
-        }
-        if (SYMB) {
-            // ---- other half: partners that found THIS agent near while scanning forward left a bit in LDS
-            group_sync<WL>();
-            if (valid) {
-                for (int w = 0; w < nbw; ++w) {
-                    unsigned m = sback[agent * nbw + w];
-                    sback[agent * nbw + w] = 0u;                               // ready for the next step
-                    while (m) {
-                        const int u = __builtin_ctz(m);
-                        m &= m - 1u;
-                        visit(agent + N - (w * 32 + u + 1));                   // partner i - r
-                    }
+                    visit(SYM ? u : agent + r0 + u);
                 }
             }
         }
@@ -850,7 +957,11 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k)
     red += (red & 3) ? 4 - (red & 3) : 0;
     b += sizeof(int) * red;
     b += sizeof(unsigned) * nwaves * kWave * 3 * (size_t)(k + 1);   // z (2 words) + Ni (1 word) per lane
-    if (g.P == 0) b += sizeof(unsigned) * (size_t)N * ((N / 2 + 31) / 32);   // SYMB backward bits
+    // bucket filter tables: [2 axes][64 cells][words] per env slot, or kSym64's per-wave rows (whichever is larger)
+    const size_t slots = g.P > 0 ? (size_t)g.epb : 1, words = g.P > 0 ? 1 : nwaves;
+    const size_t generic = (g.P > 0 && N < kBucketMinN) ? 0 : sizeof(unsigned long long) * slots * 2 * kCells * words;
+    const size_t sym = g.P > 0 ? sizeof(ulonglong2) * nwaves * kBucketRows : 0;
+    b += generic > sym ? generic : sym;
     return b;
 }
 
@@ -934,6 +1045,7 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     // far agents matter when a z row carries (v, l) of a tie-ordered agent (c = 5) or
     // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)
     const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
+    a.bucket = (g.P > 0 && p->N >= kBucketMinN && !far) ? 1 : 0;
 #if !defined(DRONESIM_NO_SYM64)
     if (p->N == 64 && !far && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
         g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane
