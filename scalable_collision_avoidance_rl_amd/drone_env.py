@@ -471,6 +471,25 @@ class drones:
         print(f"Collision cost weight (per unit of time) = {self.collision_weight} ")
         return ""
 
+    # ------------------------------------------------------------------ figures (compat.py; CPU, matplotlib)
+    def show(self, state=None, not_animate=True):
+        """Current (or given) ``[N,5]`` state on the grid (drone_env.py:404-434); returns the figure."""
+        from . import compat
+        return compat.show_state(self, None if not_animate else state, show=not_animate)
+
+    def plot(self, trajectory, episode=None):
+        """Paths + collision marks of one episode from a list of ``[N,5]`` states (drone_env.py:450-514)."""
+        from . import compat
+        return compat.plot_trajectory(self, trajectory, episode, show=True)[0]
+
+    def animate(self, trajectory, z_trajectory, deltas, episode, name="test", format="gif"):
+        """``videos/<name>.gif|mp4`` of one episode (drone_env.py:516-607)."""
+        from . import compat
+        print("\nSaving animation...")
+        full = compat.animate_trajectory(self, trajectory, z_trajectory, deltas, episode, name, format)
+        print(f"Animation saved as {full}")
+        return full
+
 
 def gradient_control(state, env, u_max=1):
     """Drop-in for the reference's module-level `gradient_control(state, env, u_max)` (drone_env.py:609-650).

@@ -9,6 +9,7 @@ of the HIP kernel in csrc/policy.hip (exact float32 on the matrix cores), includ
   DiscreteSoftmaxNN  utils.py:255-309   BatchedMLP.from_discrete_softmax(modules)
   NormalActorNN      utils.py:55-117    BatchedMLP.from_normal_actor(modules)
   CriticNN           utils.py:14-53     BatchedMLP.from_critic(modules)
+  saved ``*.pth`` lists               BatchedMLP.from_reference_file(path)
 
 `modules` are any objects exposing the reference's attribute names (`input_layer`, `hidden_layer1`, ...,
 each with `.weight [out,in]` and `.bias`), e.g. the reference's own classes or plain namespaces of tensors.
@@ -45,6 +46,36 @@ def pack_bf16_fragments(w, ksteps, nchunks, k_order="linear"):
     else:
         raise ValueError("k_order must be 'linear' or 'accumulator'")
     return frag.reshape(n, nchunks, ksteps, 64, 8).to(torch.bfloat16).contiguous()
+
+
+def stack_reference_modules(modules, kind=None):
+    """Per-agent modules -> ``(w1, b1, w2, b2, w3, b3, out_kind, sample_kind)`` with a leading agent axis
+    (CPU tensors; pure torch, no GPU needed).  ``kind``: 'discrete_softmax' | 'normal_actor' | 'critic',
+    default: recognised from the first module's attribute names."""
+    import torch
+    from .compat import network_kind
+    modules = list(modules)
+    kind = kind or network_kind(modules[0])
+    st = torch.stack
+    if kind in ("discrete_softmax", "critic"):
+        last = "out_1" if kind == "discrete_softmax" else "output_layer"
+        parts = [(_wt(m.input_layer), _wt(m.hidden_layer1), _wt(getattr(m, last))) for m in modules]
+        tensors = [st([p[layer][j] for p in parts]) for layer in range(3) for j in range(2)]
+        return (*tensors, OUT_SOFTMAX, SAMPLE_CATEGORICAL) if kind == "discrete_softmax" else (*tensors, OUT_IDENTITY, SAMPLE_NONE)
+    if kind != "normal_actor":
+        raise ValueError(f"unknown network kind {kind!r}")
+    w1, b1, w2, b2, w3, b3 = [], [], [], [], [], []
+    for m in modules:
+        a, ab = _wt(m.input_layer)
+        h1w, h1b = _wt(m.hidden_layer1); h2w, h2b = _wt(m.hidden_layer2)
+        o1w, o1b = _wt(m.out_1); o2w, o2b = _wt(m.out_2)
+        w1.append(a); b1.append(ab)
+        w2.append(torch.cat([h1w, h2w], dim=1)); b2.append(torch.cat([h1b, h2b]))
+        d = o1w.shape[1]
+        blk = torch.zeros(h1w.shape[1] + h2w.shape[1], 2 * d)
+        blk[:h1w.shape[1], :d] = o1w; blk[h1w.shape[1]:, d:] = o2w
+        w3.append(blk); b3.append(torch.cat([o1b, o2b]))
+    return st(w1), st(b1), st(w2), st(b2), st(w3), st(b3), OUT_TANH_SIGMOID, SAMPLE_GAUSSIAN
 
 
 class BatchedMLP:
@@ -93,37 +124,26 @@ class BatchedMLP:
     @classmethod
     def from_discrete_softmax(cls, modules, **kw):
         """N x DiscreteSoftmaxNN: input_layer -> hidden_layer1 -> out_1, softmax (utils.py:271-302)."""
-        import torch
-        parts = [(_wt(m.input_layer), _wt(m.hidden_layer1), _wt(m.out_1)) for m in modules]
-        st = lambda k, j: torch.stack([p[k][j] for p in parts])
-        return cls(st(0, 0), st(0, 1), st(1, 0), st(1, 1), st(2, 0), st(2, 1), OUT_SOFTMAX, SAMPLE_CATEGORICAL, **kw)
+        return cls(*stack_reference_modules(modules, "discrete_softmax"), **kw)
 
     @classmethod
     def from_critic(cls, modules, **kw):
         """N x CriticNN: input_layer -> hidden_layer1 -> output_layer, no activation (utils.py:22-53)."""
-        import torch
-        parts = [(_wt(m.input_layer), _wt(m.hidden_layer1), _wt(m.output_layer)) for m in modules]
-        st = lambda k, j: torch.stack([p[k][j] for p in parts])
-        return cls(st(0, 0), st(0, 1), st(1, 0), st(1, 1), st(2, 0), st(2, 1), OUT_IDENTITY, SAMPLE_NONE, **kw)
+        return cls(*stack_reference_modules(modules, "critic"), **kw)
 
     @classmethod
     def from_normal_actor(cls, modules, **kw):
         """N x NormalActorNN: the two heads (hidden_layer1 -> out_1 tanh, hidden_layer2 -> out_2 sigmoid,
         utils.py:64-108) become one concatenated second layer and a block-diagonal output layer."""
-        import torch
-        w1, b1, w2, b2, w3, b3 = [], [], [], [], [], []
-        for m in modules:
-            a, ab = _wt(m.input_layer)
-            h1w, h1b = _wt(m.hidden_layer1); h2w, h2b = _wt(m.hidden_layer2)
-            o1w, o1b = _wt(m.out_1); o2w, o2b = _wt(m.out_2)
-            w1.append(a); b1.append(ab)
-            w2.append(torch.cat([h1w, h2w], dim=1)); b2.append(torch.cat([h1b, h2b]))
-            d = o1w.shape[1]
-            blk = torch.zeros(h1w.shape[1] + h2w.shape[1], 2 * d)
-            blk[:h1w.shape[1], :d] = o1w; blk[h1w.shape[1]:, d:] = o2w
-            w3.append(blk); b3.append(torch.cat([o1b, o2b]))
-        s = torch.stack
-        return cls(s(w1), s(b1), s(w2), s(b2), s(w3), s(b3), OUT_TANH_SIGMOID, SAMPLE_GAUSSIAN, **kw)
+        return cls(*stack_reference_modules(modules, "normal_actor"), **kw)
+
+    @classmethod
+    def from_reference_file(cls, path, **kw):
+        """All agents' networks of one of the reference's saved files (``torch.save`` of a list of modules,
+        SAC_agents.py:404-406, e.g. ``models/discrete-A2Cactors.pth``), opened without the reference's code
+        (`compat.load_reference_modules`); the network class is recognised by its attribute names."""
+        from .compat import load_reference_modules
+        return cls(*stack_reference_modules(load_reference_modules(path)), **kw)
 
     # ------------------------------------------------------------------ evaluation
     def _run(self, z, want_out, sample, env_base=0, env=None):

@@ -1,0 +1,111 @@
+"""f4 conveniences: the reference's saved module lists load without its code; figures render
+from trajectories.  CPU only."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from tests import helpers as H  # noqa: F401
+
+
+def _fake_reference_file(tmp_path, kind):
+    """torch.save of a list of modules whose classes live in a module called `utils`, as SAC_agents.py:404-406 does."""
+    import torch
+    import torch.nn as nn
+    utils = types.ModuleType("utils")
+
+    class CriticNN(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.input_layer, self.hidden_layer1, self.output_layer = nn.Linear(6, 20), nn.Linear(20, 12), nn.Linear(12, 1)
+            self.input_layer_activation = nn.ReLU()
+
+    class DiscreteSoftmaxNN(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.input_layer, self.hidden_layer1, self.out_1 = nn.Linear(6, 20), nn.Linear(20, 12), nn.Linear(12, 8)
+            self.n_actions = 8
+
+    class NormalActorNN(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.input_layer = nn.Linear(6, 20)
+            self.hidden_layer1, self.hidden_layer2 = nn.Linear(20, 10), nn.Linear(20, 14)
+            self.out_1, self.out_2 = nn.Linear(10, 2), nn.Linear(14, 2)
+
+    for c in (CriticNN, DiscreteSoftmaxNN, NormalActorNN):
+        c.__module__ = "utils"; c.__qualname__ = c.__name__
+        setattr(utils, c.__name__, c)
+    sys.modules["utils"] = utils
+    try:
+        torch.manual_seed(0)
+        mods = [getattr(utils, kind)() for _ in range(3)]
+        path = os.path.join(tmp_path, kind + ".pth")
+        torch.save(mods, path)
+    finally:
+        del sys.modules["utils"]
+    return path, mods
+
+
+@pytest.mark.parametrize("kind,name", [("CriticNN", "critic"), ("DiscreteSoftmaxNN", "discrete_softmax"),
+                                       ("NormalActorNN", "normal_actor")])
+def test_saved_module_lists_load_without_the_reference_code(tmp_path, kind, name):
+    import torch
+    from scalable_collision_avoidance_rl_amd.compat import load_reference_modules, network_kind
+    from scalable_collision_avoidance_rl_amd.policies import stack_reference_modules
+    path, mods = _fake_reference_file(str(tmp_path), kind)
+    assert "utils" not in sys.modules
+    loaded = load_reference_modules(path)
+    assert len(loaded) == 3 and type(loaded[0]).__name__ == kind and network_kind(loaded[0]) == name
+    w1, b1, w2, b2, w3, b3, ok, sk = stack_reference_modules(loaded)
+    x = torch.randn(7, 6)
+    for i, m in enumerate(mods):                     # stacked weights reproduce the original modules' forward
+        h = torch.relu(x @ w1[i] + b1[i]); h = torch.relu(h @ w2[i] + b2[i]); y = h @ w3[i] + b3[i]
+        h0 = torch.relu(m.input_layer(x))
+        if name == "normal_actor":
+            want = torch.cat([m.out_1(torch.relu(m.hidden_layer1(h0))), m.out_2(torch.relu(m.hidden_layer2(h0)))], -1)
+        else:
+            want = getattr(m, "out_1" if name == "discrete_softmax" else "output_layer")(torch.relu(m.hidden_layer1(h0)))
+        assert torch.allclose(y, want, atol=1e-5)
+    assert (ok, sk) == {"critic": (0, 0), "discrete_softmax": (1, 1), "normal_actor": (2, 2)}[name]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/models/discrete-A2Ccritics.pth"), reason="reference artefacts absent")
+def test_real_reference_artefacts_load():
+    """The reference's own files (5 agents): critics 6 -> 200 -> 200 -> 1, discrete actors 6 -> 200 -> 200 -> 4."""
+    from scalable_collision_avoidance_rl_amd.compat import load_reference_modules
+    from scalable_collision_avoidance_rl_amd.policies import stack_reference_modules
+    crit = stack_reference_modules(load_reference_modules("/root/reference/models/discrete-A2Ccritics.pth"))
+    assert tuple(crit[0].shape) == (5, 6, 200) and tuple(crit[4].shape) == (5, 200, 1) and crit[6:] == (0, 0)
+    act = stack_reference_modules(load_reference_modules("/root/reference/models/discrete-A2Cactors.pth"))
+    assert tuple(act[2].shape) == (5, 200, 200) and tuple(act[4].shape) == (5, 200, 4) and act[6:] == (1, 1)
+
+
+class _Env:          # the attributes the figure code reads
+    n_agents, grid, drone_radius, k_closest, local_state_space = 3, [5, 5], 0.1, 2, 6
+    end_points = np.array([[4.0, 2.5, 2.5, 4.0, 1.0, 1.0]]).T
+    obstacles = np.zeros((0, 3))
+
+
+def test_figures_render_from_trajectories(tmp_path):
+    pytest.importorskip("matplotlib")
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    from scalable_collision_avoidance_rl_amd import compat
+    env, T = _Env(), 12
+    traj, ztraj = [], []
+    for t in range(T):
+        s = np.zeros((3, 5)); s[:, 4] = 0.1
+        s[:, 0] = [1 + 0.1 * t, 2.5, 3.5]; s[:, 1] = [1.0, 1.0, 1.0 + 0.05 * t]
+        if t >= 9:
+            s[1, 0] = s[0, 0] + 0.15                                    # agents 0 and 1 touch for 3 steps
+        traj.append(s)
+        ztraj.append([np.array([[s[i, 0] - 4, s[i, 1] - 2.5], [0.3, 0.1], [0.1, -0.2]]) for i in range(3)])
+    hit = compat.collision_table(traj)
+    assert hit.shape == (3, T) and hit[0, 9:].all() and hit[1, 9:].all() and not hit[2].any() and not hit[:, :9].any()
+    fig, n = compat.plot_trajectory(env, traj, episode=4)
+    assert n == 6 and "Episode 5" in fig.axes[0].get_title()
+    assert compat.show_state(env, traj[0]) is not None
+    full = compat.animate_trajectory(env, traj, ztraj, np.ones(3) * 0.5, episode=0, name="t", folder=str(tmp_path), fps=10)
+    assert os.path.getsize(full) > 1000

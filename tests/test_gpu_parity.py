@@ -838,3 +838,28 @@ def test_far_filter_paths_sparse_aliased_and_crowded(torch, N, G):
 def formation_dhat(N, G):
     from scalable_collision_avoidance_rl_amd import formation_O
     return float(formation_O(N, [G, G])[1].min())
+
+
+def test_artefact_shims_on_device(torch, tmp_path):
+    """f4: a saved list of per-agent modules -> BatchedMLP in one call; a rollout record -> the reference's
+    trajectory format (positions recovered from z row 0)."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    from scalable_collision_avoidance_rl_amd import compat
+    from tests.test_compat import _fake_reference_file
+    path, mods = _fake_reference_file(str(tmp_path), "DiscreteSoftmaxNN")
+    pol = BatchedMLP.from_reference_file(path)
+    x = torch.randn(50, 3, 6)
+    want = torch.stack([torch.softmax(m.out_1(torch.relu(m.hidden_layer1(torch.relu(m.input_layer(x[:, i]))))), -1)
+                        for i, m in enumerate(mods)], 1)
+    H.assert_close(host(pol.forward(x.cuda())), want.detach().numpy(), "from_reference_file forward")
+    N, G, E, T = 5, 5.0, 8, 6
+    a = make_env(N, G, 2, 2, np.ones(N), E, seed=3)
+    b = make_env(N, G, 2, 2, np.ones(N), E, seed=3)
+    act = torch.rand(T, E, N, 2, device="cuda:0") * 2 - 1
+    out = a.rollout(act)
+    traj, ztraj = compat.trajectory_from_rollout(a, out, e=2)
+    for t in range(T):
+        b.step(act[t])
+        H.assert_close(traj[t][:, 0:2], host(b.pos)[2], f"trajectory step {t}", atol=2e-6)
+        assert np.array_equal(np.stack(ztraj[t]).reshape(N, -1).astype(np.float32), host(b.z)[2])
+    assert len(traj) == T and traj[0].shape == (N, 5) and np.all(traj[0][:, 4] == 0.1)
