@@ -42,6 +42,13 @@
 
 #include "dronesim.h"
 
+// Translation-unit parts (csrc/Makefile): the instantiations of drone_kernel (8 k x 7 geometry/far x 3 modes)
+// compile as four parallel parts of two k values each (DRONESIM_PART = 1..4); part 0 holds everything else
+// and dispatches to them; with DRONESIM_PART undefined the whole library is this one translation unit.
+#ifndef DRONESIM_PART
+#define DRONESIM_PART (-1)
+#endif
+
 namespace {
 
 constexpr int kWave = 64;
@@ -690,6 +697,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #endif
 }
 
+}   // namespace
+
+#if DRONESIM_PART <= 0
+namespace {
+
 // ---------------------------------------------------------------------------------------
 // reset: N distinct lattice nodes per env by parallel rejection on a Philox4x32-10 stream
 // (restated integer-exactly on the CPU in oracle/drone_oracle.c:oracle_reset).
@@ -920,6 +932,7 @@ int fail(int code, const char *msg)
 
 // shared with the other translation units of the library (csrc/common.hpp); not part of the C ABI
 __attribute__((visibility("hidden"))) int dronesim_fail(int code, const char *msg) { return fail(code, msg); }
+#endif   // DRONESIM_PART <= 0
 
 namespace {
 
@@ -927,6 +940,8 @@ struct Geometry {
     int P, epb, threads, blocks, geo;
     size_t lds;
 };
+
+#if DRONESIM_PART <= 0
 
 Geometry geometry(int N, int E)
 {
@@ -979,6 +994,9 @@ int check_params(const DroneParams *p, int E)
     return DRONESIM_OK;
 }
 
+#endif   // DRONESIM_PART <= 0
+
+#if DRONESIM_PART != 0
 // more than 64 KiB of dynamic LDS (envs of several hundred agents) has to be opted into once per kernel
 template <int K, bool FAR, int MODE, int GEO>
 void launch_one(const KArgs &a, const Geometry &g, hipStream_t s)
@@ -1022,6 +1040,33 @@ void launch_k(int mode, bool far, const KArgs &a, const Geometry &g, hipStream_t
     }
 }
 
+#endif   // DRONESIM_PART != 0
+}   // namespace
+
+#if DRONESIM_PART >= 1      // this part's two k values, called from part 0
+#define DRONESIM_PART_ENTRY2(n) dronesim_launch_part##n
+#define DRONESIM_PART_ENTRY(n) DRONESIM_PART_ENTRY2(n)
+extern "C" __attribute__((visibility("hidden")))
+void DRONESIM_PART_ENTRY(DRONESIM_PART)(int k, int mode, int far, const void *a, const void *g, void *s)
+{
+    constexpr int k0 = 2 * DRONESIM_PART - 1;
+    if (k == k0) launch_k<k0>(mode, far != 0, *static_cast<const KArgs *>(a), *static_cast<const Geometry *>(g), static_cast<hipStream_t>(s));
+    else launch_k<k0 + 1>(mode, far != 0, *static_cast<const KArgs *>(a), *static_cast<const Geometry *>(g), static_cast<hipStream_t>(s));
+}
+#endif
+
+#if DRONESIM_PART == 0
+extern "C" {
+void dronesim_launch_part1(int, int, int, const void *, const void *, void *);
+void dronesim_launch_part2(int, int, int, const void *, const void *, void *);
+void dronesim_launch_part3(int, int, int, const void *, const void *, void *);
+void dronesim_launch_part4(int, int, int, const void *, const void *, void *);
+}
+#endif
+
+#if DRONESIM_PART <= 0
+namespace {
+
 int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
 {
     if (E == 0) return DRONESIM_OK;
@@ -1051,6 +1096,16 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
         g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
+#if DRONESIM_PART == 0
+    static_assert(DRONESIM_MAX_K == 8, "four parts of two k values");
+    switch ((p->k - 1) / 2) {
+    case 0: dronesim_launch_part1(p->k, mode, far, &a, &g, s); break;
+    case 1: dronesim_launch_part2(p->k, mode, far, &a, &g, s); break;
+    case 2: dronesim_launch_part3(p->k, mode, far, &a, &g, s); break;
+    case 3: dronesim_launch_part4(p->k, mode, far, &a, &g, s); break;
+    default: return fail(DRONESIM_EUNSUPPORTED, "k_closest > DRONESIM_MAX_K");
+    }
+#else
     switch (p->k) {
     case 1: launch_k<1>(mode, far, a, g, s); break;
     case 2: launch_k<2>(mode, far, a, g, s); break;
@@ -1062,6 +1117,7 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     case 8: launch_k<8>(mode, far, a, g, s); break;
     default: return fail(DRONESIM_EUNSUPPORTED, "k_closest > DRONESIM_MAX_K");
     }
+#endif
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
@@ -1215,3 +1271,4 @@ const char *dronesim_error_string(int code)
 int dronesim_version(void) { return DRONESIM_VERSION; }
 
 }   // extern "C"
+#endif   // DRONESIM_PART <= 0
