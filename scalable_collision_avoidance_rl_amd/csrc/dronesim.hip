@@ -15,16 +15,18 @@
 //             workgroup, wave-local synchronisation only.  N = 64 -> one wave per env.
 //   N  > 64 : one workgroup per env, thread = agent (N <= 1024).
 //   Every wave covers a contiguous range of global agents: streams are wave-uniform base + lane.
-//   LDS tile: the integrated positions of an env are stored TWICE back to back (x_0..x_{N-1},
-//   x_0..x_{N-1}) so that lane i reads its r-th partner j = (i + r) mod N at the wrap-free address
-//   base_i + r (immediate offsets, no self pair), in two copies one element apart so that every
-//   lane has a 16-byte aligned window (two partners per ds_read_b128).
-//   Pass 1 ("far filter", ~5 VALU/pair): squared distance against the early-out radius
-//   (dhat + l_i + l_max)^2.  A pair beyond it has d_ij = dhat_i, log term 0, no collision, and --
-//   when max(Delta) < min(dhat), the regime of every config in BASELINE.json -- is outside every
-//   Delta mask, so it contributes nothing.  Survivors become one bit per partner in a per-lane mask.
-//   Every unordered pair is scanned ONCE where that is possible: N = 64 hands the verdict to the
-//   other end as a rotated ballot (kSym64), N > 64 through an LDS bit table (SYMB).
+//   LDS tile: the integrated positions of an env, read by agent index.
+//   Pass 1 ("far filter"): a pair beyond the early-out radius reach_i = dhat_i + l_i + l_max has
+//   d_ij = dhat_i, log term 0, no collision, and -- when max(Delta) < min(dhat), the regime of every
+//   config in BASELINE.json -- is outside every Delta mask, so it contributes nothing.  Instead of testing
+//   all pairs, each env hashes its agents into 64 cells per axis (cell width >= max reach) and keeps, per
+//   cell, the mask of the agents in it (LDS, built with ds_or_b64): an agent's candidates are
+//   (masks of its x cell +-1) & (masks of its y cell +-1); those few get the exact squared-distance
+//   test.  Survivors become one bit per partner.  Crowded waves (an agent with > 10 candidates) test all
+//   partners instead (N = 64: every unordered pair once, verdict handed over as a rotated ballot);
+//   small packed envs (N < 40) and the FAR variant scan partners through relative windows of a doubled
+//   position array (lane i reads partner (i + r) mod N at the wrap-free address base_i + r, two copies
+//   one element apart so that every lane has a 16-byte aligned window).
 //   Pass 2 ("near pairs"): each lane walks ITS OWN set bits, so a wave spends
 //   max-over-lanes(popcount) iterations instead of one per partner; only here are
 //   sqrt / log / the Delta mask / the (k+1)-entry sorted neighbour list evaluated.
@@ -180,22 +182,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 {
     constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
     constexpr bool SYM = GEO == kSym64;
-    // generic bucket filter (see below): always for N > 64, for packed envs when the host asks for it (N >= 24)
+    // generic bucket filter (see below): always for N > 64, for packed envs when the host asks for it (N >= kBucketMinN)
     constexpr bool BLOCKGEO = GEO == kBlock256 || GEO == kBlock1024;
     constexpr int WMAX = GEO == kBlock1024 ? 16 : GEO == kBlock256 ? 4 : 1;   // 64-agent words per env
     static_assert(!(SYM && FAR), "the symmetric filter assumes far agents never matter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TRACE_MARK(0);
-#if defined(DRONESIM_EXP_PRIO)
-    // stagger co-resident waves: different workgroups get different issue priority, so their
-    // load / pair / store phases stop running in lockstep
-    switch ((blockIdx.x >> DRONESIM_EXP_PRIO) & 3) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-#endif
     const int N = SYM ? 64 : a.N;
     const int tid = threadIdx.x;
     const unsigned lane = tid & (kWave - 1);
@@ -623,11 +615,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 
             if (MODE != kObserve) {
                 if (MODE != kRollout || step == nsteps - 1) {                 // final state only
-#if defined(DRONESIM_EXP_POS_CACHED)
-                    (reinterpret_cast<float2 *>(a.pos) + wga0)[lane] = make_float2(xi, yi);
-#else
                     st_out2(a.pos + 2 * wga0 + 2 * lane, xi, yi);
-#endif
                     st_out2(a.vel + 2 * wga0 + 2 * lane, vxi, vyi);
                 }
                 if (!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius)) atomicOr(&sred[2 * slot + 1], 1);   // :249-251
