@@ -13,11 +13,12 @@
 //
 // Arithmetic: exact float32 on the matrix cores -- v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain
 // (no reduced precision), so results match a float32 torch reference to round-off.
-// Decomposition: ceil(E/64) x N workgroups (XCD-aware order, see xcd_work_item): one workgroup = 64 env rows of ONE agent.
-//   wave w owns every fourth 32-column chunk of the hidden layers for all 64 rows (two 32x32
-//   accumulators that share every B fragment).
-//   layer 1: A = x tile (LDS), B = W1 (global/L2)            -> h1 tile in LDS [64][h1+1]
-//   layer 2 chunk (32 columns): A = h1 (LDS), B = W2          -> relu -> per-wave LDS staging [64][33]
+// Decomposition: ceil(E/32) x N workgroups (XCD-aware order, see xcd_work_item): one workgroup = 32 env rows of ONE agent, 4 waves.
+//   wave w owns every fourth 32-column chunk of the hidden layers (one 32x32 accumulator tile).
+//   32 rows keep the workgroup at ~57 KiB of LDS, so two workgroups share a CU and one's prologue, barriers
+//   and output stage overlap the other's MFMAs (64-row workgroups -- one per CU -- measured 6-12 % slower).
+//   layer 1: A = x tile (LDS), B = W1 (global/L2)            -> h1 tile in LDS [32][h1+1]
+//   layer 2 chunk (32 columns): A = h1 (LDS), B = W2          -> relu -> per-wave LDS staging [32][33]
 //   layer 3 partial: A = staged chunk, B = W3 rows of the chunk -> accumulated in registers
 //   the four waves' partials are summed through LDS, then activation + sampling.
 // LDS row strides are odd (h1+1, 33) so the 32-row fragment reads are bank-conflict free.
@@ -30,7 +31,11 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kRows = 64;            // env rows per workgroup
+#ifndef POLICY_F32_ROWS
+#define POLICY_F32_ROWS 32
+#endif
+constexpr int kRows = POLICY_F32_ROWS;   // env rows per workgroup (32-row tiles x 4 feature waves each)
+constexpr int kThreadsF = kRows * 8;
 constexpr int kMaxOut = 32;
 
 struct FinishArgs {
@@ -197,9 +202,9 @@ __device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, 
     }
 }
 
-// 64 env rows of one agent per workgroup, 8 waves = two per SIMD (one's operand loads hide behind the other's
-// MFMAs): wave w owns feature chunks (w & 3), (w & 3) + 4, ... for the 32 rows of half (w >> 2).
-__global__ void __launch_bounds__(512) mlp3_kernel(const MArgs a)
+// kRows env rows of one agent per workgroup, 4 waves per 32-row tile: wave w owns feature chunks (w & 3),
+// (w & 3) + 4, ... of the rows of tile (w >> 2).
+__global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const MArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -209,16 +214,16 @@ __global__ void __launch_bounds__(512) mlp3_kernel(const MArgs a)
     xcd_work_item((a.E + kRows - 1) / kRows, agent, row_block);
     const int e0 = row_block * kRows;
     const int ldx = a.d_in + 1, ld1 = a.h1 + 1;
-    float *sx = reinterpret_cast<float *>(smem);                 // [64][d_in+1]
-    float *sh1 = sx + kRows * ldx;                               // [64][h1+1]
-    float *sst = sh1 + kRows * ld1;                              // [8 waves][32][33] layer-2 chunk staging,
+    float *sx = reinterpret_cast<float *>(smem);                 // [rows][d_in+1]
+    float *sh1 = sx + kRows * ldx;                               // [rows][h1+1]
+    float *sst = sh1 + kRows * ld1;                              // [waves][32][33] layer-2 chunk staging,
                                                                  // reused for the layer-3 partials
     const float *w1 = a.w1 + (size_t)agent * a.d_in * a.h1, *b1 = a.b1 + (size_t)agent * a.h1;
     const float *w2 = a.w2 + (size_t)agent * a.h1 * a.h2, *b2 = a.b2 + (size_t)agent * a.h2;
     const float *w3 = a.w3 + (size_t)agent * a.h2 * a.nout, *b3 = a.b3 + (size_t)agent * a.nout;
 
     // ---- x tile -> LDS (rows beyond E are zero)
-    for (int idx = tid; idx < kRows * a.d_in; idx += 512) {
+    for (int idx = tid; idx < kRows * a.d_in; idx += kThreadsF) {
         const int r = idx / a.d_in, c = idx - r * a.d_in;
         const int e = e0 + r;
         sx[r * ldx + c] = e < a.E ? a.x[((size_t)e * a.N + agent) * a.d_in + c] : 0.0f;
@@ -626,7 +631,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2; a.nout = m->nout;
     a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
-    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + 8 * 32 * 33);
+    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + (kThreadsF / 64) * 32 * 33);
     static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
     if (!big_lds_enabled) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -635,7 +640,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
         big_lds_enabled = true;
     }
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
-    hipLaunchKernelGGL(mlp3_kernel, dim3(((E + kRows - 1) / kRows) * m->N), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(mlp3_kernel, dim3(((E + kRows - 1) / kRows) * m->N), dim3(kThreadsF), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
