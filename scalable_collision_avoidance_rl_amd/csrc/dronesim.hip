@@ -219,13 +219,18 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     float2 u0 = make_float2(0.f, 0.f);
     int tcur = 0;
     float xFx = 0.f, xFy = 0.f, dhat = 1.f, delta_i = 0.f, li = 0.f;
+    // the pointers of the first loads must sit in SGPRs before the branch: left alone, the compiler sinks their
+    // kernel-argument fetch into it and every wave pays a scalar-load round trip before its HBM loads go out
+    const float2 *pos_in = reinterpret_cast<const float2 *>(a.pos) + wga0;
+    const float2 *vel_in = reinterpret_cast<const float2 *>(MODE == kObserve ? a.vel : a.act) + wga0;
+    asm volatile("" : : "s"(pos_in), "s"(vel_in));
     if (valid) {
-        const float2 p = (reinterpret_cast<const float2 *>(a.pos) + wga0)[lane];
+        const float2 p = pos_in[lane];
         if (MODE == kObserve) {
-            const float2 v = (reinterpret_cast<const float2 *>(a.vel) + wga0)[lane];
+            const float2 v = vel_in[lane];
             vxi = v.x; vyi = v.y;
         } else {
-            u0 = (reinterpret_cast<const float2 *>(a.act) + wga0)[lane];
+            u0 = vel_in[lane];
             if (agent == 0) tcur = a.t[env];
         }
         const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
@@ -284,7 +289,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // pass-1 window of this lane starts at dup index agent + (odd r): pick the copy where that is even
     const float2 *pwin = (agent & 1) ? spos_env + agent + 1 : spos_env + stride + agent + 2;
     const int nsteps = (MODE == kRollout) ? a.T : 1;
-    const bool staged = a.c == 2 && !masked;                 // z / Ni leave through LDS as full lines
+    // c = 5 rows carry (v, l) of tie-ordered agents, which forces the FAR variant on the host: every other
+    // instantiation knows c = 2 at compile time (no dead c = 5 code, and no conservative s_waitcnt for its loads)
+    const int zc = FAR ? a.c : 2;
+    const bool staged = zc == 2 && !masked;                  // z / Ni leave through LDS as full lines
 
     // ---- candidate list (fused rollout of kSym64 only): the far filter is run with radius reach + skin and
     // its verdicts are kept in registers until some agent of the env has moved more than skin/2 from where
@@ -591,7 +599,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 nbv[kth] = real ? (int)j : -1;
             }
             if (!staged) {                                                    // c = 5 rows / masked observe
-                const int c = a.c;
+                const int c = zc;
                 float *zr = a.z + (so + wga0 + lane) * (size_t)((K + 1) * c);
                 int *nb = a.nbr_idx + (so + wga0 + lane) * (size_t)(K + 1);
 #pragma unroll
