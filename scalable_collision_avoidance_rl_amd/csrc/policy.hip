@@ -204,8 +204,10 @@ __device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, 
 
 // kRows env rows of one agent per workgroup, 4 waves per 32-row tile: wave w owns feature chunks (w & 3),
 // (w & 3) + 4, ... of the rows of tile (w >> 2).
-__global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const MArgs a)
+__global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, int N, int d_in, const MArgs rest)
 {
+    MArgs a = rest;                      // leading scalars are preloaded into SGPRs at wave launch (csrc/Makefile)
+    a.x = x; a.E = E; a.N = N; a.d_in = d_in;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -350,8 +352,10 @@ __device__ __forceinline__ void store_chunk(const f32x16 (&acc)[kTiles], const f
 }
 
 template <int NC1>                       // 32-feature chunks of the first hidden layer (h1 <= 32 NC1)
-__global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const MArgsB a)
+__global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const float *x, int E, int N, int d_in, const MArgsB rest)
 {
+    MArgsB a = rest;                     // leading scalars are preloaded into SGPRs at wave launch (csrc/Makefile)
+    a.x = x; a.E = E; a.N = N; a.d_in = d_in;
     // occupancy first: h1 <= 256 leaves LDS for four workgroups per CU, which needs <= 128 VGPRs (ring of 4);
     // wider layers fit three (two beyond h1 = 352), where 168 VGPRs allow weight fragments 8 k-steps ahead
     constexpr int kRing = NC1 <= 8 ? 4 : 8;
@@ -539,7 +543,8 @@ int launch_bf16(const MArgsB &a, size_t lds, hipStream_t stream)
             return dronesim_fail(DRONESIM_ELAUNCH, "cannot enable 160 KiB of dynamic LDS for mlp3_bf16_kernel");
         big_lds_enabled = true;
     }
-    hipLaunchKernelGGL(mlp3_bf16_kernel<NC1>, dim3(((a.E + kRowsB - 1) / kRowsB) * a.N), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(mlp3_bf16_kernel<NC1>, dim3(((a.E + kRowsB - 1) / kRowsB) * a.N), dim3(256), lds, stream,
+                       a.x, a.E, a.N, a.d_in, a);
     return DRONESIM_OK;
 }
 
@@ -640,7 +645,8 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
         big_lds_enabled = true;
     }
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
-    hipLaunchKernelGGL(mlp3_kernel, dim3(((E + kRows - 1) / kRows) * m->N), dim3(kThreadsF), lds, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(mlp3_kernel, dim3(((E + kRows - 1) / kRows) * m->N), dim3(kThreadsF), lds, static_cast<hipStream_t>(stream),
+                       a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
