@@ -196,6 +196,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     static_assert(!(SYM && FAR), "the symmetric filter assumes far agents never matter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TRACE_MARK(0);
+#if defined(DRONESIM_TRACE)
+    const long long trace_rt0 = (long long)__builtin_amdgcn_s_memrealtime();   // 100 MHz, the same clock on every XCC
+#endif
     const int N = SYM ? 64 : a.N;
     const int tid = threadIdx.x;
     const unsigned lane = tid & (kWave - 1);
@@ -695,8 +698,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): all stores acknowledged
     TRACE_MARK(6);
     if (a.trace && (threadIdx.x & 63) == 0)
-        a.trace[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + 7] =
-            (long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);   // HW_REG_XCC_ID[3:0]
+        a.trace[((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8 + 7] =    // entry and exit on the global clock
+            (trace_rt0 & 0xffffffffll) | ((long long)__builtin_amdgcn_s_memrealtime() << 32);
 #endif
 }
 

@@ -32,17 +32,17 @@ lib.dronesim_debug_set_trace(None)
 t = trace.cpu().numpy().astype(np.float64)
 t0 = t[:, 0].min()
 names = ["entry", "loaded+LDS written", "after barrier", "pairs done", "stores issued", "end", "stores acked"]
-print(f"{spec}: {waves} waves, event time {e0.elapsed_time(e1)*1e3:.1f} us; timestamps in ticks since first wave entry")
-for k, nm in enumerate(names):
-    col = t[:, k] - t0
-    print(f"  {nm:>20}: min {col.min():9.0f}  median {np.median(col):9.0f}  max {col.max():9.0f}")
+print(f"{spec}: {waves} waves, event time {e0.elapsed_time(e1)*1e3:.1f} us; phase lengths in s_memtime ticks (per-wave differences; the counter is not synchronised across XCCs)")
 d = np.diff(t[:, :7], axis=1)
 for k in range(6):
     print(f"  phase {names[k]:>20} -> {names[k+1]:<20}: median {np.median(d[:, k]):8.0f}  p95 {np.percentile(d[:, k], 95):8.0f}")
-xcc = t[:, 7].astype(int)
-for x in sorted(set(xcc)):
-    sel = xcc == x
-    e = t[sel, 0]; f = t[sel, 6]
-    print(f"  XCC {x}: {sel.sum():5d} waves; entry spread {e.max()-e.min():8.0f}; first entry -> last ack {f.max()-e.min():8.0f} ticks")
-span = (t[:, 6].max() - t0)
-print(f"  total span {span:.0f} ticks; if 100 MHz ticks -> {span/100:.2f} us; if 2.4 GHz -> {span/2400:.2f} us")
+rt = trace[:, 7].cpu().numpy()                    # s_memrealtime (100 MHz, global): entry in the low word, exit in the high word
+ent = (rt & 0xffffffff).astype(np.int64); ext = ((rt >> 32) & 0xffffffff).astype(np.int64)
+e = (ent - ent.min()) * 0.01; x = (ext - ent.min()) * 0.01
+print(f"  global clock (us since the first wave entered): entry p50 {np.median(e):.2f} p95 {np.percentile(e, 95):.2f} max {e.max():.2f}; "
+      f"exit p5 {np.percentile(x, 5):.2f} p50 {np.median(x):.2f} max {x.max():.2f}")
+late = x >= np.percentile(x, 98)                  # what makes the last 2 % of the waves late?
+ph = d / 2400.0                                   # phases in us at ~2.4 GHz
+print(f"  last 2 % of the waves vs all (us): entry {e[late].mean():.2f} vs {e.mean():.2f}" +
+      "".join(f"; {nm} {ph[late, k].mean():.2f} vs {ph[:, k].mean():.2f}"
+              for k, nm in enumerate(["load", "sync", "pairs", "epilogue", "copy-out", "ack"])))
