@@ -20,15 +20,21 @@ class EpisodeStats:
     def __init__(self, device):
         import torch
         self.vec = torch.zeros(len(STAT_FIELDS), dtype=torch.float64, device=device)
+        self._upd = torch.zeros_like(self.vec)          # one step's contribution, written in place
+        self._shape = None
 
     def add_step(self, rewards, true_rewards, n_collisions):
-        """rewards/true_rewards [E,N], n_collisions [E] of one step (what train_problem.py:98-100 sums)."""
-        E, N = rewards.shape
-        self.vec[0] += rewards.sum(dtype=self.vec.dtype)
-        self.vec[1] += true_rewards.sum(dtype=self.vec.dtype)
-        self.vec[2] += n_collisions.sum(dtype=self.vec.dtype)
-        self.vec[3] += E * N
-        self.vec[4] += E
+        """rewards/true_rewards [E,N], n_collisions [E] of one step (what train_problem.py:98-100 sums).
+        Four small launches (three reductions writing straight into a staging vector, one add), no host sync."""
+        import torch
+        if self._shape != tuple(rewards.shape):          # the constant entries, once per batch shape
+            E, N = rewards.shape
+            self._upd[3], self._upd[4] = E * N, E
+            self._shape = tuple(rewards.shape)
+        torch.sum(rewards.reshape(-1), dim=0, dtype=self.vec.dtype, out=self._upd[0])
+        torch.sum(true_rewards.reshape(-1), dim=0, dtype=self.vec.dtype, out=self._upd[1])
+        torch.sum(n_collisions.reshape(-1), dim=0, dtype=self.vec.dtype, out=self._upd[2])
+        self.vec += self._upd
 
     def reduce(self, group=None):
         """All-gather every rank's vector and sum locally -> dict of global figures (same on all ranks)."""
