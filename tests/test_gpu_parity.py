@@ -863,3 +863,39 @@ def test_artefact_shims_on_device(torch, tmp_path):
         H.assert_close(traj[t][:, 0:2], host(b.pos)[2], f"trajectory step {t}", atol=2e-6)
         assert np.array_equal(np.stack(ztraj[t]).reshape(N, -1).astype(np.float32), host(b.z)[2])
     assert len(traj) == T and traj[0].shape == (N, 5) and np.all(traj[0][:, 4] == 0.1)
+
+
+@pytest.mark.parametrize("N,G", [(64, 28.0), (48, 24.0), (200, 200.0)])
+def test_non_finite_and_huge_coordinates_are_contained(torch, N, G):
+    """State the reference never guards against: an agent at +-inf, NaN, +-1e30 or 3e38 must not disturb the other
+    envs of the launch (bit-identical to a launch without the poisoned envs), must not crash or hang the far
+    filter's cell hashing, and an agent that is merely far away (1e6) is handled like any other far agent."""
+    rng = np.random.default_rng(N + 7)
+    E = 24
+    dl = np.ones(N) * 0.6 * formation_dhat(N, G)
+    pos = (G / 2 + (rng.random((E, N, 2)) - 0.5) * 0.6 * G).astype(np.float32)
+    bad = pos.copy()
+    for e, v in enumerate([np.inf, -np.inf, np.nan, 1e30, -1e30, 3e38]):
+        bad[e, e % N, e % 2] = v
+    bad[6, 3] = (1e6, -1e6)                                    # far but ordinary: still exact vs the oracle
+    a, b = make_env(N, G, 2, 2, dl, E), make_env(N, G, 2, 2, dl, E)
+    a.set_state(pos); b.set_state(bad)
+    act = torch.zeros(E, N, 2, device="cuda:0")
+    ra, rb = a.step(act), b.step(act)
+    torch.cuda.synchronize()
+    clean = slice(7, E)
+    for name in ("reward", "true_reward", "z", "nbr_idx", "n_coll", "done", "pos"):
+        assert torch.equal(getattr(a, name)[clean], getattr(b, name)[clean]), name
+    orc = Oracle(N, [G, G], 2, dl, True, threads=4)
+    p6 = host(b.pos)[6:7].astype(np.float64)
+    ref = orc.observe(p6, np.zeros((1, N, 2)))
+    if orc.margins(p6)[0] > H.MARGIN:
+        np.testing.assert_array_equal(host(b.nbr_idx)[6], ref["nbr_idx"][0])
+        assert host(b.n_coll)[6] == ref["n_coll"][0]
+        far_free = np.arange(N) != 3                           # the far agent's own goal term is ~1e11: compare the others
+        H.assert_close(host(b.reward)[6][far_free], ref["reward"][0][far_free], "reward next to a far agent")
+    # poisoned envs: the unaffected agents of the same env keep finite rewards and valid neighbour lists
+    r = host(b.reward)[:6]
+    assert np.isfinite(r).all()                                # nan_to_num semantics (drone_env.py:287-288)
+    nb = host(b.nbr_idx)[:6]
+    assert ((nb >= -1) & (nb < N)).all()
