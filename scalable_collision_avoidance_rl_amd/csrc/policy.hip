@@ -38,6 +38,13 @@ constexpr int kRows = POLICY_F32_ROWS;   // env rows per workgroup (32-row tiles
 constexpr int kThreadsF = kRows * 8;
 constexpr int kMaxOut = 32;
 
+#if defined(DRONESIM_TRACE)
+long long *g_policy_trace = nullptr;     // developer builds only: [workgroups][4 waves][8] timestamps
+#define PT(k) do { if (a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PT(k) do { } while (0)
+#endif
+
 struct FinishArgs {
     int N, nout, out_kind, sample_kind;
     float *out, *act;
@@ -48,6 +55,9 @@ struct FinishArgs {
 };
 
 struct MArgs {
+#if defined(DRONESIM_TRACE)
+    long long *trace;
+#endif
     int E, N, d_in, h1, h2, nout;
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     FinishArgs fin;
@@ -167,13 +177,16 @@ constexpr int kU = 8;                  // k-steps (of 2) per pipeline stage
 
 struct Frag { float b[kU], a[kU]; };
 
-__device__ __forceinline__ void load_frag(Frag &f, const float *Arow, const float *__restrict__ Bcol, int ldb, int kbase)
+template <bool CHECK>                                   // CHECK: k >= K reads as zero (the ragged last stage)
+__device__ __forceinline__ void load_frag(Frag &f, const float *Arow, const float *__restrict__ Bcol, int ldb, int kbase, int K)
 {
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
         const int k = kbase + 2 * u;
-        f.b[u] = Bcol[(size_t)k * ldb];
-        f.a[u] = Arow[k];
+        const int kc = CHECK ? min(k, K - 1) : k;          // clamped address, value masked below: no branches
+        const float b = Bcol[(size_t)kc * ldb], av = Arow[kc];
+        f.b[u] = (!CHECK || k < K) ? b : 0.0f;
+        f.a[u] = (!CHECK || k < K) ? av : 0.0f;
     }
 }
 
@@ -186,19 +199,21 @@ __device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, 
     const int Kmain = K - K % (2 * kU);                    // whole pipeline stages, no bounds checks inside
     if (Kmain > 0) {
         Frag cur, nxt;
-        load_frag(cur, Arow, Bcol, ldb, kk);
+        load_frag<false>(cur, Arow, Bcol, ldb, kk, K);
         for (int k0 = 0; k0 < Kmain; k0 += 2 * kU) {
             const bool more = k0 + 2 * kU < Kmain;         // wave-uniform
-            if (more) load_frag(nxt, Arow, Bcol, ldb, k0 + 2 * kU + kk);
+            if (more) load_frag<false>(nxt, Arow, Bcol, ldb, k0 + 2 * kU + kk, K);
 #pragma unroll
             for (int u = 0; u < kU; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[u], cur.b[u], acc, 0, 0, 0);
             if (more) cur = nxt;
         }
     }
-    for (int k0 = Kmain; k0 < K; k0 += 2) {                // tail (K not a multiple of 16)
-        const int k = k0 + kk;
-        const bool kok = k < K;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kok ? Arow[k] : 0.0f, kok ? Bcol[(size_t)k * ldb] : 0.0f, acc, 0, 0, 0);
+    if (Kmain < K) {                                       // ragged rest (and all of a K < 16 layer) as ONE masked stage:
+        Frag t;                                            // its loads are in flight together instead of one per MFMA
+        load_frag<true>(t, Arow, Bcol, ldb, Kmain + kk, K);
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+            if (Kmain + 2 * u < K) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.a[u], t.b[u], acc, 0, 0, 0);   // wave-uniform
     }
 }
 
@@ -224,6 +239,7 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     const float *w2 = a.w2 + (size_t)agent * a.h1 * a.h2, *b2 = a.b2 + (size_t)agent * a.h2;
     const float *w3 = a.w3 + (size_t)agent * a.h2 * a.nout, *b3 = a.b3 + (size_t)agent * a.nout;
 
+    PT(0);
     // ---- x tile -> LDS (rows beyond E are zero)
     for (int idx = tid; idx < kRows * a.d_in; idx += kThreadsF) {
         const int r = idx / a.d_in, c = idx - r * a.d_in;
@@ -231,19 +247,66 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
         sx[r * ldx + c] = e < a.E ? a.x[((size_t)e * a.N + agent) * a.d_in + c] : 0.0f;
     }
     __syncthreads();
+    PT(1);
 
     const int col = lane & 31;
-    // ---- layer 1
-    for (int c0 = cw * 32; c0 < a.h1; c0 += 128) {
-        f32x16 acc = {0};
-        tile_gemm(acc, sx + rh * 32 * ldx, ldx, w1 + c0, a.h1, a.d_in, a.h1 - c0, lane);
-        const bool ok = c0 + col < a.h1;
-        const float bias = ok ? b1[c0 + col] : 0.0f;
+    // ---- layer 1: K = d_in is tiny, so the operands of ALL of this wave's chunks (<= 4: h1 <= 512) and their
+    //      biases are requested together -- one global round trip for the layer instead of two per chunk
+    if (a.d_in <= 2 * kU) {
+        constexpr int kL1 = 4;
+        const float *Arow = sx + (rh * 32 + (lane & 31)) * ldx;
+        Frag f[kL1];
+        float bias[kL1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (ok) sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc[r] + bias, 0.0f);
+        for (int i = 0; i < kL1; ++i) {
+            const int c0 = cw * 32 + 128 * i;
+            if (c0 < a.h1) {                                     // wave-uniform
+                load_frag<true>(f[i], Arow, w1 + c0 + min(col, a.h1 - c0 - 1), a.h1, lane >> 5, a.d_in);
+                bias[i] = c0 + col < a.h1 ? b1[c0 + col] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kL1; ++i) {
+            const int c0 = cw * 32 + 128 * i;
+            if (c0 < a.h1) {
+                f32x16 acc = {0};
+#pragma unroll
+                for (int u = 0; u < kU; ++u)
+                    if (2 * u < a.d_in) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].a[u], f[i].b[u], acc, 0, 0, 0);
+                if (c0 + col < a.h1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc[r] + bias[i], 0.0f);
+                }
+            }
+        }
+    } else {
+        for (int c0 = cw * 32; c0 < a.h1; c0 += 128) {
+            const bool ok = c0 + col < a.h1;
+            const float bias = ok ? b1[c0 + col] : 0.0f;
+            f32x16 acc = {0};
+            tile_gemm(acc, sx + rh * 32 * ldx, ldx, w1 + c0, a.h1, a.d_in, a.h1 - c0, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (ok) sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc[r] + bias, 0.0f);
+        }
     }
+    PT(2);
     __syncthreads();
+    PT(3);
+
+    // the output stage's inputs (4 lanes per row), requested now so that their latency hides behind layers 2 + 3
+    uint32_t tval = 0u, epval = 0u;
+    float b3v[kQ];
+    {
+        const int e = e0 + (tid >> 2);
+        if (tid < 4 * kRows && e < a.E && a.fin.sample_kind != 0) {
+            if (a.fin.t_dev) tval = (uint32_t)a.fin.t_dev[e];
+            if (a.fin.episode_dev) epval = (uint32_t)a.fin.episode_dev[e];
+        }
+#pragma unroll
+        for (int i = 0; i < kQ; ++i) b3v[i] = (tid & 3) + 4 * i < a.nout ? b3[(tid & 3) + 4 * i] : 0.0f;
+    }
 
     // ---- layers 2 + 3 fused over this wave's column chunks
     f32x16 y = {0};
@@ -263,9 +326,11 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    PT(4);
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = y[r];   // this wave's partial outputs
     __syncthreads();
+    PT(5);
 
     // ---- output activation + sampling: four lanes per env row
     if (tid < 4 * kRows) {
@@ -279,15 +344,14 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
             const int j = part + 4 * i;
             float v = 0.0f;
             if (j < a.nout) {
-                v = b3[j];
+                v = b3v[i];
 #pragma unroll
                 for (int w = 0; w < 4; ++w) v += sst[((rhh * 4 + w) * 32 + rr) * 33 + j];
             }
             yv[i] = v;
         }
-        const uint32_t tval = (a.fin.sample_kind != 0 && a.fin.t_dev) ? (uint32_t)a.fin.t_dev[e] : 0u;
-        const uint32_t epval = (a.fin.sample_kind != 0 && a.fin.episode_dev) ? (uint32_t)a.fin.episode_dev[e] : 0u;
         finish_quad(a.fin, yv, e, agent, part, tval, epval);
+        PT(6);
     }
 }
 
@@ -314,12 +378,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int kRowsB = 64, kTiles = 2;   // 64 env rows (2 row tiles) per workgroup
 constexpr int kLdx = 24;                 // bf16 per row of the x tile
-#if defined(DRONESIM_TRACE)
-long long *g_policy_trace = nullptr;     // developer builds only: [workgroups][4 waves][8] timestamps
-#define PT(k) do { if (a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PT(k) do { } while (0)
-#endif
 
 struct MArgsB {
 #if defined(DRONESIM_TRACE)
@@ -633,6 +691,9 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
     if (E == 0) return DRONESIM_OK;
     MArgs a{};
+#if defined(DRONESIM_TRACE)
+    a.trace = g_policy_trace;
+#endif
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2; a.nout = m->nout;
     a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);

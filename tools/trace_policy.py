@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: per-wave phase timestamps of the bf16 policy kernel (needs a -DDRONESIM_TRACE build,
-selected with DRONESIM_LIB=build/libdronesim_trace.so).  usage: trace_policy.py [softmax16|gaussian|critic] [c3]"""
+selected with DRONESIM_LIB=build/libdronesim_trace.so).  usage: trace_policy.py [softmax16|gaussian|critic] [c3] [bf16|f32]"""
 import ctypes as C
 import os
 import sys
@@ -18,12 +18,13 @@ kind = sys.argv[1] if len(sys.argv) > 1 else "softmax16"
 spec = sys.argv[2] if len(sys.argv) > 2 else "c3"
 N, E, G, delta = PRESETS[spec]
 env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1)
-pol, shape = rnd_policy(kind, N, 6, env.device, "bf16")
+prec = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+pol, shape = rnd_policy(kind, N, 6, env.device, prec)
 run = (lambda: pol.sample_action(env.z)) if pol.sample_kind else (lambda: pol.forward(env.z))
 for _ in range(3):
     run()
 torch.cuda.synchronize()
-blocks = ((E + 63) // 64) * N
+blocks = ((E + (63 if prec == "bf16" else 31)) // (64 if prec == "bf16" else 32)) * N
 trace = torch.zeros(blocks, 4, 8, dtype=torch.int64, device="cuda")
 lib = _native.lib()
 lib.dronesim_debug_set_policy_trace.argtypes = [C.c_void_p]
@@ -36,13 +37,14 @@ t = trace.cpu().numpy().astype(np.float64)
 names = ["entry", "prologue + barrier", "layer 1 done", "barrier", "h1 tile in registers", "layers 2+3 done",
          "partials + barriers", "finish"]
 print(f"{kind} {spec} {shape}: {blocks} workgroups, event time {e0.elapsed_time(e1)*1e3:.1f} us; ticks ~ 100 MHz or core clock, see ratio")
-life = t[:, :, 6] - t[:, :, 0]
+last = 6 if prec == "bf16" else 5
+life = t[:, :, last] - t[:, :, 0]
 print(f"  wave lifetime entry -> partials: median {np.median(life):.0f} p95 {np.percentile(life, 95):.0f} ticks")
-for k in range(1, 7):
+for k in range(1, last + 1):
     d = t[:, :, k] - t[:, :, k - 1]
     per = " ".join(f"w{w}:{np.median(d[:, w]):7.0f}" for w in range(4))
     print(f"  {names[k]:>24}: median {np.median(d):8.0f}  p95 {np.percentile(d, 95):8.0f}   {per}")
-d = (t[:, :, 7] - t[:, :, 6])[t[:, :, 7] > 0]
-print(f"  {names[7]:>24}: median {np.median(d):8.0f}  p95 {np.percentile(d, 95):8.0f}")
+d = (t[:, :, last + 1] - t[:, :, last])[t[:, :, last + 1] > 0]
+print(f"  {names[last + 1]:>24}: median {np.median(d):8.0f}  p95 {np.percentile(d, 95):8.0f}")
 span = t.max() - t[:, :, 0].min()
 print(f"  kernel span {span:.0f} ticks -> {span / (e0.elapsed_time(e1) * 1e3):.1f} ticks/us")
