@@ -235,12 +235,15 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     const float2 *vel_in = reinterpret_cast<const float2 *>(MODE == kObserve ? a.vel : a.act) + wga0;
     asm volatile("" : : "s"(pos_in), "s"(vel_in));
     if (valid) {
-        const float2 p = pos_in[lane];
+        // read once per launch: streaming loads (the state and the actions do not displace anything in L2)
+        const f32x2 pl = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(pos_in) + lane);
+        const float2 p = make_float2(pl.x, pl.y);
         if (MODE == kObserve) {
             const float2 v = vel_in[lane];
             vxi = v.x; vyi = v.y;
         } else {
-            u0 = vel_in[lane];
+            const f32x2 ul = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(vel_in) + lane);
+            u0 = make_float2(ul.x, ul.y);
             if (agent == 0) tcur = a.t[env];
         }
         const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
