@@ -332,8 +332,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 vxi = u.x; vyi = u.y;                         // drone_env.py:238
             }
             spos_env[agent] = make_float2(xi, yi);
-            if (!use_bucket) {                                // relative partner windows (dup index agent + r)
-                spos_env[agent + N] = make_float2(xi, yi);
+            if (!use_bucket && !SYM) {                        // relative partner windows (dup index agent + r);
+                spos_env[agent + N] = make_float2(xi, yi);    // kSym64 writes them only when its fallback runs
                 if (!FAR) {
                     spos_env[stride + agent + 1] = make_float2(xi, yi);
                     spos_env[stride + agent + N + 1] = make_float2(xi, yi);
@@ -512,7 +512,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         }
                     } else {
                     // (c) crowded env: every unordered pair once -- lane i tests partners i+1..i+32 and the
-                    //     verdict reaches the other end as a rotated ballot
+                    //     verdict reaches the other end as a rotated ballot.  The doubled / shifted copies of
+                    //     the positions that those windows read are made here, on the rare path only.
+                    spos_env[agent + N] = make_float2(xi, yi);
+                    spos_env[stride + agent + 1] = make_float2(xi, yi);
+                    spos_env[stride + agent + N + 1] = make_float2(xi, yi);
+                    group_sync<true>();
                     unsigned mf = 0u, mb = 0u;
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
