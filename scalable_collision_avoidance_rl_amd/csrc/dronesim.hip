@@ -657,11 +657,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #else
         if (staged && valid) {                                // this lane's rows -> the wave's staging area
 #endif
+            float2 *zrow = reinterpret_cast<float2 *>(stage_z) + lane * (K + 1);   // one base each, immediate offsets
+            unsigned *nrow = stage_n + lane * kNRow;
 #pragma unroll
-            for (int kth = 0; kth <= K; ++kth) {
-                reinterpret_cast<float2 *>(stage_z)[lane * (K + 1) + kth] = make_float2(zrx[kth], zry[kth]);
-                stage_n[lane * kNRow + kth] = (unsigned)nbv[kth];
-            }
+            for (int kth = 0; kth <= K; ++kth) zrow[kth] = make_float2(zrx[kth], zry[kth]);
+#pragma unroll
+            for (int kth = 0; kth <= K; ++kth) nrow[kth] = (unsigned)nbv[kth];
         }
         TRACE_MARK(4);
         group_sync<WL>();
