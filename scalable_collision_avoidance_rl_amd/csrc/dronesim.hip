@@ -236,14 +236,25 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     asm volatile("" : : "s"(pos_in), "s"(vel_in));
     if (valid) {
         // read once per launch: streaming loads (the state and the actions do not displace anything in L2)
-        const f32x2 pl = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(pos_in) + lane);
-        const float2 p = make_float2(pl.x, pl.y);
+        // (measured: -0.1 us at C3; the workgroup-per-env shapes at BASELINE size -- C5 shard, 2 MB of state --
+        // are 0.2 us faster with plain loads, and a run-time choice costs more than either)
+        float2 p;
+        if (BLOCKGEO) {
+            p = pos_in[lane];
+        } else {
+            const f32x2 pl = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(pos_in) + lane);
+            p = make_float2(pl.x, pl.y);
+        }
         if (MODE == kObserve) {
             const float2 v = vel_in[lane];
             vxi = v.x; vyi = v.y;
         } else {
-            const f32x2 ul = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(vel_in) + lane);
-            u0 = make_float2(ul.x, ul.y);
+            if (BLOCKGEO) {
+                u0 = vel_in[lane];
+            } else {
+                const f32x2 ul = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(vel_in) + lane);
+                u0 = make_float2(ul.x, ul.y);
+            }
             if (agent == 0) tcur = a.t[env];
         }
         const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
