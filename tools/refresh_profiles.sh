@@ -19,6 +19,7 @@ prof() {   # name, command...
 }
 (cd $ROOT && prof c3_bench python bench.py --steps 1000 --warmup 100 --no-cpu-baseline)
 cp $(find $OUT/prof_c3_bench -name '*domain_stats.csv' | head -1) $OUT/${TAG}_c3_bench_domain_stats.csv 2>/dev/null
+(cd $ROOT && prof c3_kbench python tools/kbench.py c3)
 (cd $ROOT && prof rollout python tools/rbench.py c3 c5)
 (cd $ROOT && prof c3_policy python tools/pbench.py c3)
 for c in FETCH_SIZE WRITE_SIZE; do
