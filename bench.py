@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
+    ap.add_argument("--graph-episodes", type=int, default=5,
+                    help="episodes (200 steps + statistic + reset each) captured per hipGraph")
     ap.add_argument("--policy", default="random", choices=["random", "softmax16", "gaussian"],
                     help="action source: pre-generated U(-1,1) actions (the graded workload) or a batched per-agent "
                          "policy evaluated on the env's observation every step (BASELINE configs[4] uses 'gaussian')")
@@ -165,21 +167,22 @@ def main():
 
     # optional hipGraph: one episode (200 steps + reset) captured once, replayed
     graph = None
+    g_len = T_ep * max(1, min(args.graph_episodes, args.steps // T_ep))     # steps per captured graph
     if not args.no_graph and args.steps >= T_ep:
         while step_no % T_ep:                        # align to an episode boundary (untimed)
             one_step(step_no); step_no += 1
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):               # the per-env episode counters live on the device, so
-            for s in range(T_ep):                   # every replayed reset draws fresh initial states
+            for s in range(g_len):                  # every replayed reset draws fresh initial states
                 one_step(s)
 
     barrier()
     t0 = time.perf_counter()
     done = 0
     if graph is not None:
-        while done + T_ep <= args.steps:
-            graph.replay(); done += T_ep
+        while done + g_len <= args.steps:
+            graph.replay(); done += g_len
     while done < args.steps:
         one_step(step_no)
         step_no += 1; done += 1
@@ -241,7 +244,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "n_agents": N, "envs_per_gpu": e_gpu, "n_envs_total": E_global,
                        "grid": G, "delta": delta, "k_closest": 2, "simplify_zstate": True,
-                       "launch": "hipGraph replay (200 steps + reset per graph)" if graph is not None else "eager",
+                       "launch": f"hipGraph replay ({g_len // T_ep} x (200 steps + statistic + reset) per graph)" if graph is not None else "eager",
                        "actions": "pre-generated U(-1,1)^2, resident in HBM" if policy is None else
                                   f"batched per-agent {args.policy} policy (random-init, {args.policy_precision} MFMA) on the observation",
                        "parallelism": f"env-shard x{world}"},

@@ -131,6 +131,15 @@ int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, c
 int dronesim_control(const DroneParams *p, int kind, const float *pos, float *act, float u_max,
                      int E, void *stream);
 
+/* The statistic the rollout loop logs per step (train_problem.py:98-100, 118-120), accumulated on the device:
+ *   acc[0] += sum reward, acc[1] += sum true_reward, acc[2] += sum n_coll, acc[3] += E N, acc[4] += E   (float64)
+ * reward / true_reward [E][N], n_coll [E] as written by dronesim_step.  One launch, fixed summation order
+ * (bit-reproducible).  scratch: DRONESIM_STATS_SCRATCH_DOUBLES doubles of device memory, zero-initialised once by
+ * the caller and owned by one accumulator.  Multi-GPU runs all-gather `acc` (the path's only exchange).            */
+#define DRONESIM_STATS_SCRATCH_DOUBLES 193
+int dronesim_episode_stats(const float *reward, const float *true_reward, const int32_t *n_coll, int E, int N,
+                           double *acc, double *scratch, void *stream);
+
 /* Learner-side reductions over a stored rollout, buffers laid out [T][E][N] like the
  * outputs of dronesim_rollout / T calls of dronesim_step:
  *   dronesim_returns    Monte-Carlo return  G[t] = r[t] + gamma G[t+1],  G[T-1] = r[T-1]

@@ -21,7 +21,8 @@ MAX_K = 8
 MAX_AGENTS = 1024
 
 # every symbol include/dronesim.h declares (tests check the .so exports all of them)
-SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
+STATS_SCRATCH_DOUBLES = 193          # DRONESIM_STATS_SCRATCH_DOUBLES (include/dronesim.h)
+SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_episode_stats", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -80,6 +81,7 @@ def lib():
     L.dronesim_rollout.argtypes = [P] + [vp] * 10 + [i32, i32, vp]
     L.dronesim_control.argtypes = [P, i32, vp, vp, f32, i32, vp]
     L.dronesim_control.restype = C.c_int
+    L.dronesim_episode_stats.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     L.dronesim_returns.argtypes = [vp, vp, f32, vp, i32, i32, i32, vp]
     L.dronesim_advantage.argtypes = [vp, vp, vp, vp, f32, vp, i32, i32, i32, i32, vp]
     L.dronesim_returns.restype = L.dronesim_advantage.restype = C.c_int

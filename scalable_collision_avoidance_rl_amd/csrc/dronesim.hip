@@ -944,6 +944,47 @@ __global__ void __launch_bounds__(256) advantage_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// The logged statistic of one step (train_problem.py:98-100: sums of rewards, true rewards and collisions),
+// accumulated in float64 into acc[5] = (sum r, sum true r, sum collisions, agent-steps, env-steps).
+// One launch: every workgroup reduces a slice to three partial sums in `scratch`; the workgroup that
+// arrives last adds the partials IN INDEX ORDER (a fixed summation order: bit-reproducible run to run).
+constexpr int kStatBlocks = 64;
+
+__global__ void __launch_bounds__(256) stats_kernel(const float *__restrict__ reward, const float *__restrict__ true_reward,
+                                                    const int *__restrict__ n_coll, int E, int N, double *acc,
+                                                    double *scratch)
+{
+    __shared__ double sh[3][4];
+    __shared__ bool last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t n = (size_t)E * N;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) {
+        s0 += (double)reward[i];
+        s1 += (double)true_reward[i];
+    }
+    for (int e = blockIdx.x * 256 + tid; e < E; e += gridDim.x * 256) s2 += (double)n_coll[e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) { sh[0][wave] = s0; sh[1][wave] = s1; sh[2][wave] = s2; }
+    __syncthreads();
+    unsigned *ticket = reinterpret_cast<unsigned *>(scratch + 3 * kStatBlocks);
+    if (tid == 0) {
+        for (int k = 0; k < 3; ++k) scratch[k * kStatBlocks + blockIdx.x] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && tid < 3) {
+        __threadfence();
+        double t = 0.0;
+        for (int b = 0; b < (int)gridDim.x; ++b) t += __builtin_nontemporal_load(scratch + tid * kStatBlocks + b);
+        acc[tid] += t;
+        if (tid == 0) { acc[3] += (double)E * N; acc[4] += (double)E; *ticket = 0u; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 thread_local char g_err[256] = "";
 #if defined(DRONESIM_TRACE)
 long long *g_trace = nullptr;
@@ -1273,6 +1314,19 @@ int dronesim_advantage(const float *G, const float *V, const int32_t *nbr_idx, c
     const size_t cols = (size_t)E * N;
     hipLaunchKernelGGL(advantage_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        G, V, nbr_idx, done, gamma, w, T, E, N, K1);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
+}
+
+int dronesim_episode_stats(const float *reward, const float *true_reward, const int32_t *n_coll, int E, int N,
+                           double *acc, double *scratch, void *stream)
+{
+    if (!reward || !true_reward || !n_coll || !acc || !scratch || E < 0 || N < 1)
+        return fail(DRONESIM_EINVAL, "dronesim_episode_stats: bad argument");
+    if (E == 0) return DRONESIM_OK;
+    hipLaunchKernelGGL(stats_kernel, dim3(kStatBlocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reward, true_reward, n_coll, E, N, acc, scratch);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

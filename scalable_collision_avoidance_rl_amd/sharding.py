@@ -9,6 +9,8 @@ per episode -- or per K steps -- makes the global figures available on every ran
 message is tens of bytes: latency-bound, kept off the per-step path."""
 from __future__ import annotations
 
+import ctypes as C
+
 from .drone_env import shard_range  # noqa: F401  (re-exported)
 
 STAT_FIELDS = ("sum_reward", "sum_true_reward", "sum_collisions", "agent_steps", "env_steps")
@@ -20,21 +22,29 @@ class EpisodeStats:
     def __init__(self, device):
         import torch
         self.vec = torch.zeros(len(STAT_FIELDS), dtype=torch.float64, device=device)
-        self._upd = torch.zeros_like(self.vec)          # one step's contribution, written in place
-        self._shape = None
+        self._scratch = None                            # device scratch of dronesim_episode_stats (CUDA tensors)
 
     def add_step(self, rewards, true_rewards, n_collisions):
         """rewards/true_rewards [E,N], n_collisions [E] of one step (what train_problem.py:98-100 sums).
-        Four small launches (three reductions writing straight into a staging vector, one add), no host sync."""
+        Device tensors: one launch of `dronesim_episode_stats` (fixed summation order, no host sync).
+        Host tensors (the CPU tests of the exchange): plain torch sums."""
         import torch
-        if self._shape != tuple(rewards.shape):          # the constant entries, once per batch shape
-            E, N = rewards.shape
-            self._upd[3], self._upd[4] = E * N, E
-            self._shape = tuple(rewards.shape)
-        torch.sum(rewards.reshape(-1), dim=0, dtype=self.vec.dtype, out=self._upd[0])
-        torch.sum(true_rewards.reshape(-1), dim=0, dtype=self.vec.dtype, out=self._upd[1])
-        torch.sum(n_collisions.reshape(-1), dim=0, dtype=self.vec.dtype, out=self._upd[2])
-        self.vec += self._upd
+        E, N = rewards.shape
+        if rewards.is_cuda:
+            from . import _native
+            if self._scratch is None:
+                self._scratch = torch.zeros(_native.STATS_SCRATCH_DOUBLES, dtype=torch.float64, device=self.vec.device)
+            r, tr = rewards.contiguous(), true_rewards.contiguous()
+            nc = n_collisions.to(torch.int32).contiguous()
+            with torch.cuda.device(self.vec.device):
+                rc = _native.lib().dronesim_episode_stats(r.data_ptr(), tr.data_ptr(), nc.data_ptr(), E, N,
+                                                          self.vec.data_ptr(), self._scratch.data_ptr(),
+                                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _native.check(rc, "dronesim_episode_stats")
+            return
+        self.vec += torch.stack([rewards.sum(dtype=self.vec.dtype), true_rewards.sum(dtype=self.vec.dtype),
+                                 n_collisions.sum(dtype=self.vec.dtype),
+                                 torch.tensor(float(E * N), dtype=self.vec.dtype), torch.tensor(float(E), dtype=self.vec.dtype)])
 
     def reduce(self, group=None):
         """All-gather every rank's vector and sum locally -> dict of global figures (same on all ranks)."""

@@ -899,3 +899,34 @@ def test_non_finite_and_huge_coordinates_are_contained(torch, N, G):
     assert np.isfinite(r).all()                                # nan_to_num semantics (drone_env.py:287-288)
     nb = host(b.nbr_idx)[:6]
     assert ((nb >= -1) & (nb < N)).all()
+
+
+def test_episode_statistic_kernel(torch):
+    """dronesim_episode_stats: float64 sums of one step's rewards / true rewards / collisions in one launch,
+    accumulated over calls, bit-reproducible, usable inside a captured graph."""
+    from scalable_collision_avoidance_rl_amd.sharding import EpisodeStats
+    g = torch.Generator(device="cuda:0").manual_seed(2)
+    for E, N in [(4096, 64), (1, 2), (777, 5), (300, 256)]:
+        r = torch.randn(E, N, device="cuda:0", generator=g) * 30
+        tr = torch.randn(E, N, device="cuda:0", generator=g) * 30
+        nc = torch.randint(0, 7, (E,), device="cuda:0", generator=g, dtype=torch.int32)
+        a, b = EpisodeStats("cuda:0"), EpisodeStats("cuda:0")
+        for _ in range(3):
+            a.add_step(r, tr, nc); b.add_step(r, tr, nc)
+        torch.cuda.synchronize()
+        want = np.array([3 * float(r.double().sum()), 3 * float(tr.double().sum()), 3 * int(nc.sum()), 3 * E * N, 3 * E])
+        np.testing.assert_allclose(host(a.vec), want, rtol=1e-12, atol=1e-9)
+        assert torch.equal(a.vec, b.vec)                                   # fixed summation order
+    st = EpisodeStats("cuda:0")
+    st.add_step(r, tr, nc)                                                 # scratch allocated before capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st.add_step(r, tr, nc)
+    for _ in range(4):
+        graph.replay()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(host(st.vec)[3:], [5 * E * N, 5 * E])
+    with pytest.raises(RuntimeError):
+        _ = st._scratch is not None and __import__("scalable_collision_avoidance_rl_amd")._native.check(
+            __import__("scalable_collision_avoidance_rl_amd")._native.lib().dronesim_episode_stats(None, None, None, 1, 1, None, None, None), "x")
