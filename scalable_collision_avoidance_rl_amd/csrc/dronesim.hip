@@ -902,6 +902,10 @@ __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
 // ---------------------------------------------------------------------------------------
 // Learner-side scans over a stored rollout [T][E][N] (SAC_agents.py:304-307, 333-351).  One thread per
 // (env, agent) column; consecutive threads touch consecutive addresses at every t (coalesced streams).
+// One thread per (env, agent) column walks the T axis.  The streams are touched once (streaming loads / stores) and
+// kStageT time steps are requested together before the sequential recurrence consumes them.
+constexpr int kStageT = 8;
+
 __global__ void __launch_bounds__(256) returns_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done,
                                                       float gamma, float *__restrict__ G, int T, int E, int N)
 {
@@ -910,11 +914,23 @@ __global__ void __launch_bounds__(256) returns_kernel(const float *__restrict__ 
     if (col >= EN) return;
     const size_t e = col / N;
     float g = 0.0f;
-    for (int t = T - 1; t >= 0; --t) {
-        const float r = reward[(size_t)t * EN + col];
-        const bool last = t == T - 1 || (done != nullptr && done[(size_t)t * E + e] != 0);
-        g = last ? r : fmaf(g, gamma, r);                     // :306  Gt[t] = Gt[t+1]*discount + r[t]
-        G[(size_t)t * EN + col] = g;
+    for (int t0 = T - 1; t0 >= 0; t0 -= kStageT) {
+        float r[kStageT];
+        bool last[kStageT];
+#pragma unroll
+        for (int u = 0; u < kStageT; ++u) {
+            const int t = t0 - u;
+            r[u] = t >= 0 ? __builtin_nontemporal_load(reward + (size_t)t * EN + col) : 0.0f;
+            last[u] = t == T - 1 || (done != nullptr && t >= 0 && done[(size_t)t * E + e] != 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kStageT; ++u) {
+            const int t = t0 - u;
+            if (t >= 0) {
+                g = last[u] ? r[u] : fmaf(g, gamma, r[u]);     // :306  Gt[t] = Gt[t+1]*discount + r[t]
+                __builtin_nontemporal_store(g, G + (size_t)t * EN + col);
+            }
+        }
     }
 }
 
