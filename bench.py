@@ -3,10 +3,17 @@
 
 A "step" is one env.step() of the batched environment: one launch of the fused HIP kernel
 over all E envs of this rank (integrate -> all-pairs distance -> Delta mask -> reward ->
-k-nearest localized state -> done), every API output written.  Actions are synthetic
-U(-1,1)^2 (RandomAgent, SAC_agents.py:22), pre-generated and resident in HBM before the
-timed region; at every episode end (200 steps, drone_env.py:30) the envs are reset on
-device inside the timed region, as train_problem.py:132 does.
+k-nearest localized state -> done), every API output written, the per-episode statistic the
+rollout loop logs (train_problem.py:98-100) accumulated on EVERY step by the kernel itself, and
+envs whose episode ends (200 steps, drone_env.py:30) reset + re-observed inside the same launch
+(train_problem.py:132).  Actions are synthetic U(-1,1)^2 (RandomAgent, SAC_agents.py:22),
+pre-generated and resident in HBM before the timed region.
+
+Timing: the K requested steps are captured ONCE as a hipGraph (whatever K is) and the timed region
+replays that graph `repeats` times -- enough for >= 0.5 s -- between the two barriers, so a short
+`--steps 20` run measures the same thing as a long one: value = N * E * K * repeats / elapsed and
+ms_per_step = elapsed / (K * repeats).  Every ~200 steps the path's only exchange runs inside the
+timed region: one fixed-order reduction of the per-env episode records + one all-gather (RCCL).
 
 Default workload = BASELINE.json configs[2] (N=64 x E=4096 per GPU, Delta=1.0, G=28): the
 configuration the headline target (>= 1e7 agent-steps/s on 1 GPU) is quoted on; weak scaling:
@@ -31,6 +38,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_AGENT_STEP = 76        # reads pos 8 + act 8; writes pos 8, vel 8, r 4, true_r 4, z 24, nbr 12
 BYTES_PER_ENV_STEP = 13          # n_coll 4 + done 1 + t read/write 8
+BYTES_PER_ENV_STEP_RECORD = 64   # episode layer: the hot 32 bytes of the env's DroneEpisodeAcc record, read + written
 
 WORKLOADS = {
     #        N    E/GPU  G      Delta  label
@@ -52,6 +60,23 @@ def pmc_traffic(workload):
         return float(json.load(open(files[-1]))["traffic_bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def reference_record(workload):
+    """The reference's OWN `drones.step()` timing at this shape (tools/time_reference.py, measured in the build
+    container where /root/reference exists; it cannot travel to the GPU box) -- attached beside the live figure
+    of the C port so that both CPU numbers stand next to the GPU one."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu.json")))
+        sh = rec["shapes"][workload]
+        return {"kind": "reference", "source": "profiles/reference_cpu.json (tools/time_reference.py)",
+                "host": rec["host"]["cpu"], "where": rec["host"]["where"],
+                "one_core_agent_steps_per_s": sh["one_core"]["agent_steps_per_s"],
+                "one_core_ms_per_step": sh["one_core"]["ms_per_step"],
+                "whole_host_agent_steps_per_s": sh["whole_host"]["agent_steps_per_s"],
+                "whole_host_cores": sh["whole_host"]["cores"]}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(N, G, delta, budget_s=12.0):
@@ -89,8 +114,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
-    ap.add_argument("--graph-episodes", type=int, default=5,
-                    help="episodes (200 steps + statistic + reset each) captured per hipGraph")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of the timed region (graph replays)")
+    ap.add_argument("--no-episode-layer", action="store_true",
+                    help="plain dronesim_step launches (no per-step statistic, explicit reset kernel every 200 steps)")
     ap.add_argument("--policy", default="random", choices=["random", "softmax16", "gaussian"],
                     help="action source: pre-generated U(-1,1) actions (the graded workload) or a batched per-agent "
                          "policy evaluated on the env's observation every step (BASELINE configs[4] uses 'gaussian')")
@@ -103,7 +129,7 @@ def main():
     import torch
     import torch.distributed as dist
     from scalable_collision_avoidance_rl_amd import drones, max_time_steps
-    from scalable_collision_avoidance_rl_amd.sharding import EpisodeStats
+    from scalable_collision_avoidance_rl_amd.sharding import reduce_episode_records, summarize_episodes, all_gather_stats
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,15 +152,16 @@ def main():
     if args.envs_per_gpu:
         e_gpu = args.envs_per_gpu
     E_global = e_gpu * world
+    layer = not args.no_episode_layer
     env = drones(N, 0, [G, G], "O", k_closest=2, deltas=np.ones(N) * delta, simplify_zstate=True,
-                 n_envs=E_global, device=dev, seed=1234, rank=rank, world_size=world, batched=True)
+                 n_envs=E_global, device=dev, seed=1234, rank=rank, world_size=world, batched=True,
+                 auto_reset=layer, track_episodes=True)
     E = env.n_envs
     T_ep = max_time_steps
 
     # synthetic actions, resident in HBM: one episode's worth, reused every episode
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = torch.rand(T_ep, E, N, 2, device=dev, generator=g) * 2 - 1
-    stats = EpisodeStats(dev)                       # what train_problem.py:98-100 logs, kept on device
 
     policy = None
     if args.policy != "random":                     # random-init per-agent networks of the reference's shapes
@@ -147,13 +174,20 @@ def main():
 
     def one_step(s):
         if policy is None:
-            res = env.step(pool[s % T_ep])
+            env.step(pool[s % T_ep])
         else:                                       # obs -> sample_action -> step (SAC_agents.py:170-180, train_problem.py:91-94)
             act, _ = policy.sample_action(env.z, env=env)
-            res = env.step(act)
-        if (s + 1) % T_ep == 0:                     # episode end: sample the statistic, reset (train_problem.py:132)
-            stats.add_step(res.rewards, res.true_rewards, res.n_collisions)
+            env.step(act)
+        if not layer and (s + 1) % T_ep == 0:       # plain path: explicit reset kernel + observe (train_problem.py:132)
             env.reset(renew_obstacles=False)
+
+    # the path's only exchange (train_problem.py:118-121: what is logged per episode), off the per-step path:
+    # local fixed-order reduction of the episode records on the step stream, then ONE all-gather of 8 doubles
+    exchanges = []
+
+    def exchange():
+        tot = env.episode_totals()                  # one launch on the current stream; device tensor [8]
+        exchanges.append(all_gather_stats(tot, async_op=True))   # RCCL on its own stream; the rollout is not held up
 
     def barrier():
         torch.cuda.synchronize()
@@ -164,30 +198,61 @@ def main():
     step_no = 0
     for _ in range(args.warmup):
         one_step(step_no); step_no += 1
+    torch.cuda.synchronize()
 
-    # optional hipGraph: one episode (200 steps + reset) captured once, replayed
+    # secondary figure: the same K steps launched eagerly from Python (host launch latency included)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(step_no); step_no += 1
+    barrier()
+    eager_elapsed = time.perf_counter() - t0
+
+    # the K steps as ONE hipGraph.  All episode state (t, episode counters, records, RNG stream position) lives on
+    # the device, so every replay continues the rollout: episodes end, are logged and restart inside the replays.
     graph = None
-    g_len = T_ep * max(1, min(args.graph_episodes, args.steps // T_ep))     # steps per captured graph
-    if not args.no_graph and args.steps >= T_ep:
-        while step_no % T_ep:                        # align to an episode boundary (untimed)
-            one_step(step_no); step_no += 1
+    K = args.steps
+    if not args.no_graph:
+        if not layer:
+            while step_no % T_ep:                   # plain path resets by step index: align the capture to an episode
+                one_step(step_no); step_no += 1
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):               # the per-env episode counters live on the device, so
-            for s in range(g_len):                  # every replayed reset draws fresh initial states
+        with torch.cuda.graph(graph):
+            for s in range(K):
                 one_step(s)
+        for _ in range(2):                          # untimed replays: instantiate + clocks
+            graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); graph.replay(); torch.cuda.synchronize()
+        one = max(time.perf_counter() - t0, 1e-6)
+        repeats = max(1, int(np.ceil(args.min_seconds / one)))
+    else:
+        repeats = 1
+    log_every = max(1, T_ep // K) if K < T_ep else 1     # replays between two exchanges (~ once per episode)
 
     barrier()
     t0 = time.perf_counter()
-    done = 0
     if graph is not None:
-        while done + g_len <= args.steps:
-            graph.replay(); done += g_len
-    while done < args.steps:
-        one_step(step_no)
-        step_no += 1; done += 1
+        for r in range(repeats):
+            graph.replay()
+            if (r + 1) % log_every == 0:
+                exchange()
+    else:
+        for s in range(K):
+            one_step(step_no); step_no += 1
+        exchange()
+    for _, work in exchanges:                       # every exchange of the timed region has completed
+        if work is not None:
+            work.wait()
     barrier()
     elapsed = time.perf_counter() - t0
+    total_steps = K * repeats
+    # final exchange: global per-episode figures (the same reduction + all-gather as inside the timed region)
+    summary = reduce_episode_records(env)
+    summary["exchanges_in_timed_region"] = len(exchanges)
+    last = exchanges[-1][0].to(dev) if exchanges else None
+    summary["last_timed_exchange_episodes"] = None if last is None else float(last.double().sum(0)[4])
 
     # Duration of the dominant kernel (drone_kernel<step>) per launch, by HIP events on the launch stream
     # (torch's current stream = the stream handed to dronesim_step): events bracket a hipGraph holding
@@ -224,41 +289,45 @@ def main():
     except RuntimeError:                               # e.g. not enough memory for the [T, ...] outputs
         ro_us = None
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    el = torch.tensor([elapsed, eager_elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    # the path's only exchange: all-gather of the global reward statistic (RCCL over xGMI when world > 1)
-    summary = stats.reduce()
-    elapsed = float(el.item())
+    elapsed, eager_elapsed = float(el[0].item()), float(el[1].item())
 
     if rank == 0:
-        agent_steps = N * E_global * args.steps
+        agent_steps = N * E_global * total_steps
         value = agent_steps / elapsed
-        bytes_launch = BYTES_PER_AGENT_STEP * N * E + BYTES_PER_ENV_STEP * E
+        bytes_launch = BYTES_PER_AGENT_STEP * N * E + (BYTES_PER_ENV_STEP + (BYTES_PER_ENV_STEP_RECORD if layer else 0)) * E
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.workload) if e_gpu == WORKLOADS[args.workload][1] else (None, None)
         out = {
             "metric": "env agent-steps/sec (n_agents x n_envs x steps)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "repeats": repeats, "timed_steps": total_steps, "timed_seconds": elapsed,
+            "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "n_agents": N, "envs_per_gpu": e_gpu, "n_envs_total": E_global,
                        "grid": G, "delta": delta, "k_closest": 2, "simplify_zstate": True,
-                       "launch": f"hipGraph replay ({g_len // T_ep} x (200 steps + statistic + reset) per graph)" if graph is not None else "eager",
+                       "launch": (f"hipGraph of the {K} requested steps, replayed {repeats}x in the timed region" if graph is not None else "eager"),
+                       "episode_layer": ("per-step statistic + in-kernel auto-reset (dronesim_step_ex)" if layer else
+                                         "plain dronesim_step + reset kernel every 200 steps"),
                        "actions": "pre-generated U(-1,1)^2, resident in HBM" if policy is None else
                                   f"batched per-agent {args.policy} policy (random-init, {args.policy_precision} MFMA) on the observation",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "drone_kernel<K=2,FAR=0,step>", "kernel_ms": kern_ms,
+                         "kernel": "drone_kernel<K=2,FAR=0,step,%s>" % ("episode layer" if layer else "plain"), "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
             "episode_end_stats": summary,
+            "eager": {"value": N * E_global * args.steps / eager_elapsed, "ms_per_step": eager_elapsed / args.steps * 1e3,
+                      "note": "the same K steps launched one by one from Python (host launch latency included)"},
             "fused_rollout": None if ro_us is None else {
                 "us_per_step_per_gpu": ro_us, "agent_steps_per_s_per_gpu": N * E / ro_us * 1e6,
                 "note": "dronesim_rollout: 200 steps per launch, 52 B/agent-step (no per-step state write-back)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, G, delta, args.cpu_budget)
+            out["cpu_baseline"]["reference"] = reference_record(args.workload)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -26,7 +26,8 @@
  *  - Return value: 0 on success, a negative DRONESIM_E* code otherwise; nothing
  *    is thrown across the ABI.  dronesim_last_error() gives a thread-local
  *    description of the last failure.
- *  - Re-entrant; no global mutable state besides that thread-local string.
+ *  - Re-entrant; the only mutable state is that thread-local string and a per-device record of which kernels
+ *    have been opted into > 64 KiB of dynamic LDS (hipFuncSetAttribute; guarded by a mutex).
  *  - One process drives one GPU; multi-GPU runs shard the E axis across
  *    processes (env_base keeps random streams independent of the sharding).
  */
@@ -39,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DRONESIM_VERSION 100           /* 0.1.0 */
+#define DRONESIM_VERSION 200           /* 0.2.0 */
 #define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
 #define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
 
@@ -119,6 +120,81 @@ int dronesim_reset(const DroneParams *p, int div_x, int div_y, float pitch,
 int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
                      float *reward, float *true_reward, float *z, int32_t *nbr_idx,
                      int32_t *n_coll, uint8_t *done, int E, int T, void *stream);
+
+/* ---- episode bookkeeping on the device (round 2) -------------------------------------------------------
+ * The rollout loop logs, per episode, the sums it accumulates on EVERY step (train_problem.py:72-74, 98-100,
+ * 118-121):  total_episode_reward += mean(rewards), total_true_episode_reward += mean(true_rewards),
+ * total_episode_collisions += n_collisions, t_iter += 1.  DroneEpisodeAcc is that record, one per env, kept in
+ * device memory and updated by the step kernel itself (the per-env reward sums are one fixed-order wave reduction
+ * in the kernel's epilogue: bit-reproducible, no extra launch, 48 B of traffic per env-step).
+ *   ep_*    the episode in progress.  ep_return / ep_true_return hold sum_t sum_i r_i: DIVIDE BY N for the
+ *           reference's figure (it adds the mean over agents each step).
+ *   done_*  totals over the episodes this env has completed; `episodes` counts them.  An episode is retired
+ *           (ep_* added into done_*, ep_* cleared) when the env is reset: by the step kernel itself under
+ *           auto_reset, or by dronesim_reset_ex.
+ * The caller zero-initialises the records once.  dronesim_episode_reduce sums them over the envs of a rank (fixed
+ * order); multi-GPU runs all-gather that 8-double vector -- the path's only exchange.                         */
+typedef struct DroneEpisodeAcc {
+    double ep_return;           /* sum over steps of sum_i reward_i            train_problem.py:98  */
+    double ep_true_return;      /* same for true_reward                         :99                  */
+    int32_t ep_collisions;      /* sum of n_collisions                          :100                 */
+    int32_t ep_len;             /* steps of the episode in progress (t_iter)    :110                 */
+    int32_t episodes;           /* completed episodes                                                */
+    int32_t reserved;
+    double done_return;         /* totals over completed episodes               :118-121             */
+    double done_true_return;
+    int64_t done_collisions;
+    int64_t done_len;
+} DroneEpisodeAcc;              /* 64 bytes, one cache line per env */
+
+/* Episode control of the *_ex entry points.  acc may be NULL (no bookkeeping).  auto_reset != 0: an env whose
+ * `done` fires (drone_env.py:251) is re-sampled (exactly as dronesim_reset would: same Philox stream, so the
+ * fresh states do not depend on which of the two did it), its record retired, its t zeroed and its observation
+ * recomputed INSIDE the same launch -- what train_problem.py:132 does after the `while not finished` loop.
+ * reward / true_reward / n_coll / done of that step still describe the finished episode's last transition;
+ * pos / vel / t / z / nbr_idx hold the new episode's first state and observation.
+ * The lattice (div_x, div_y, pitch), seed, env_base and episode[] have the meaning they have in
+ * dronesim_reset and are needed when auto_reset or in-kernel random actions are used.                        */
+typedef struct DroneEpisodeCtl {
+    DroneEpisodeAcc *acc;       /* [E] device records, or NULL                                       */
+    int32_t auto_reset;
+    int32_t div_x;              /* lattice of dronesim_reset: nodes per axis ...              */
+    int32_t div_y;
+    float pitch;                /* ... and node spacing                                          */
+    uint64_t seed;
+    int64_t env_base;
+    int32_t *episode;           /* [E] device, resets seen per env (in/out)                          */
+} DroneEpisodeCtl;
+
+/* dronesim_step / dronesim_rollout with episode bookkeeping and optional in-kernel auto-reset.  ctl == NULL
+ * behaves exactly like the plain entry points.                                                               */
+int dronesim_step_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, float *pos, float *vel, int32_t *t,
+                     const float *act, float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                     int32_t *n_coll, uint8_t *done, int E, void *stream);
+int dronesim_rollout_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, float *pos, float *vel, int32_t *t,
+                        const float *act, float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                        int32_t *n_coll, uint8_t *done, int E, int T, void *stream);
+
+/* T fused steps whose actions are drawn INSIDE the kernel: RandomAgent.forward, SAC_agents.py:9-22
+ * (clip(-1 + 2 rand(2), -1, 1)) for every agent and step, from the counter-based stream
+ *   philox4x32-10(ctr = (agent, env_base + e, t[e] >> 1, episode[e]); key = (seed.lo ^ 0x52414E44, seed.hi)),
+ *   words 2 (t & 1), 2 (t & 1) + 1 -> a = -1 + (w >> 8) * 2^-23   (uniform on the 2^24-point grid of [-1, 1))
+ * keyed by the env's own step and episode counters: no action pool is read (44 B per agent-step instead of 52),
+ * results do not depend on how the env axis is sharded or on T.  ctl is required (seed, env_base, episode; acc
+ * and auto_reset optional).  act_out ([T][E][N][2], may be NULL) records the actions drawn.  Other buffers as
+ * dronesim_rollout; any of reward / true_reward / n_coll may be NULL.                                         */
+int dronesim_rollout_random(const DroneParams *p, const DroneEpisodeCtl *ctl, float *pos, float *vel, int32_t *t,
+                            float *act_out, float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                            int32_t *n_coll, uint8_t *done, int E, int T, void *stream);
+
+/* dronesim_reset that also retires the episode records of the envs it resets (those with ep_len > 0).        */
+int dronesim_reset_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, const uint8_t *mask,
+                      float *pos, float *vel, int32_t *t, int32_t *node_out, int E, void *stream);
+
+/* out[0..7] = sums over the E records of (done_return, done_true_return, done_collisions, done_len, episodes,
+ * ep_return, ep_true_return, ep_len), float64, one launch, fixed summation order (bit-reproducible).          */
+#define DRONESIM_EPISODE_REDUCE_DOUBLES 8
+int dronesim_episode_reduce(const DroneEpisodeAcc *acc, int E, double *out, void *stream);
 
 /* Classical controllers, batched (deterministic action sources for rollouts and tests):
  *   kind DRONESIM_CONTROL_PROPORTIONAL  proportional_control(state, env)      drone_env.py:652-679

@@ -343,6 +343,31 @@ uint32_t oracle_philox_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
     return o[0];
 }
 
+void oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    philox4x32_10(c0, c1, c2, c3, k0, k1, out);
+}
+
+/* RandomAgent.forward: np.clip(-1 + 2*np.random.rand(n_actions), -1, 1)          SAC_agents.py:9-22
+ * NumPy's stream is not reproduced; the build draws the same distribution from the
+ * counter-based stream documented at dronesim_rollout_random (include/dronesim.h):
+ *   philox4x32-10(ctr = (agent, env_base + e, t[e] >> 1, episode[e]); key = (seed.lo ^ "RAND", seed.hi)),
+ *   words 2 (t & 1), 2 (t & 1) + 1;  a = -1 + (w >> 8) * 2^-23  -- exact in float32 and float64 alike.
+ * act[E][N][2] for the CURRENT t / episode of every env.                                              */
+void oracle_rand_actions(int N, int E, uint64_t seed, int64_t env_base, const int32_t *t,
+                         const int32_t *episode, double *act)
+{
+    const uint32_t k0 = (uint32_t)seed ^ 0x52414E44u, k1 = (uint32_t)(seed >> 32);
+    for (int e = 0; e < E; ++e)
+        for (int i = 0; i < N; ++i) {
+            uint32_t o[4];
+            philox4x32_10((uint32_t)i, (uint32_t)(env_base + e), (uint32_t)t[e] >> 1, (uint32_t)episode[e], k0, k1, o);
+            const int h = (t[e] & 1) ? 2 : 0;
+            act[((size_t)e * N + i) * 2 + 0] = -1.0 + (double)(o[h] >> 8) * 0x1p-23;
+            act[((size_t)e * N + i) * 2 + 1] = -1.0 + (double)(o[h + 1] >> 8) * 0x1p-23;
+        }
+}
+
 /* Draw N distinct nodes out of M = div_x*div_y for env `env_gid`:
  *   round r: every unsettled agent i proposes node = mulhi32(philox(ctr = (i, r, env_gid,
  *            episode[e]); key = (seed_lo, seed_hi)).word0, M), episode[e] = number of resets

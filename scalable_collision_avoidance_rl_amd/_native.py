@@ -22,7 +22,9 @@ MAX_AGENTS = 1024
 
 # every symbol include/dronesim.h declares (tests check the .so exports all of them)
 STATS_SCRATCH_DOUBLES = 193          # DRONESIM_STATS_SCRATCH_DOUBLES (include/dronesim.h)
+EPISODE_REDUCE_DOUBLES = 8           # DRONESIM_EPISODE_REDUCE_DOUBLES
 SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_episode_stats", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
+           "dronesim_step_ex", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -35,6 +37,20 @@ class DroneParams(C.Structure):
                 ("radius_min", C.c_float), ("radius_max", C.c_float),
                 ("xF", C.c_void_p), ("d_hat", C.c_void_p), ("delta", C.c_void_p),
                 ("radius", C.c_void_p)]
+
+
+class DroneEpisodeAcc(C.Structure):
+    """Mirror of `struct DroneEpisodeAcc` (include/dronesim.h): one 64-byte record per env."""
+    _fields_ = [("ep_return", C.c_double), ("ep_true_return", C.c_double),
+                ("ep_collisions", C.c_int32), ("ep_len", C.c_int32), ("episodes", C.c_int32), ("reserved", C.c_int32),
+                ("done_return", C.c_double), ("done_true_return", C.c_double),
+                ("done_collisions", C.c_int64), ("done_len", C.c_int64)]
+
+
+class DroneEpisodeCtl(C.Structure):
+    """Mirror of `struct DroneEpisodeCtl` (include/dronesim.h)."""
+    _fields_ = [("acc", C.c_void_p), ("auto_reset", C.c_int32), ("div_x", C.c_int32), ("div_y", C.c_int32),
+                ("pitch", C.c_float), ("seed", C.c_uint64), ("env_base", C.c_int64), ("episode", C.c_void_p)]
 
 
 class DroneMlp(C.Structure):
@@ -90,8 +106,15 @@ def lib():
     L.dronesim_mlp_forward_bf16.argtypes = [C.POINTER(DroneMlpBf16), vp, vp, vp, vp, u64, u64, i64, vp, vp, i32, vp]
     L.dronesim_mlp_forward_bf16.restype = C.c_int
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
-    for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset",
-                 "dronesim_version"):
+    PC = C.POINTER(DroneEpisodeCtl)
+    L.dronesim_step_ex.argtypes = [P, PC] + [vp] * 10 + [i32, vp]
+    L.dronesim_rollout_ex.argtypes = [P, PC] + [vp] * 10 + [i32, i32, vp]
+    L.dronesim_rollout_random.argtypes = [P, PC] + [vp] * 10 + [i32, i32, vp]
+    L.dronesim_reset_ex.argtypes = [P, PC] + [vp] * 5 + [i32, vp]
+    L.dronesim_episode_reduce.argtypes = [vp, i32, vp, vp]
+    for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset", "dronesim_step_ex",
+                 "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
+                 "dronesim_episode_stats", "dronesim_version"):
         getattr(L, name).restype = C.c_int
     L.dronesim_last_error.restype = C.c_char_p
     L.dronesim_error_string.restype = C.c_char_p

@@ -41,12 +41,15 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
+#include <mutex>
 
 #include "dronesim.h"
+#include "common.hpp"
 
-// Translation-unit parts (csrc/Makefile): the instantiations of drone_kernel (8 k x 7 geometry/far x 3 modes)
-// compile as four parallel parts of two k values each (DRONESIM_PART = 1..4); part 0 holds everything else
-// and dispatches to them; with DRONESIM_PART undefined the whole library is this one translation unit.
+// Translation-unit parts (csrc/Makefile): the instantiations of drone_kernel (8 k x 7 geometry/far x 5 mode/bookkeeping
+// combinations) compile as eight parallel parts, one k value each (DRONESIM_PART = 1..8); part 0 holds everything
+// else and dispatches to them; with DRONESIM_PART undefined the whole library is this one translation unit.
 #ifndef DRONESIM_PART
 #define DRONESIM_PART (-1)
 #endif
@@ -87,8 +90,18 @@ struct KArgs {
     int bucket;                     // packed geometry: use the bucket far filter (N >= 24)
     int uniform;                    // all agents share d_hat, Delta and radius (host-known): constants come
     float dhat_u, delta_u, radius_u;   //   from the kernel arguments, no per-agent table is read
+    // episode bookkeeping / in-kernel reset / in-kernel random actions (DroneEpisodeCtl; all off when zero)
+    double *acc;                    // DroneEpisodeAcc[E] as 8 x 8 bytes per env, or nullptr
+    int auto_reset, rand_act;
+    int div_y;
+    uint32_t lat_M, key0, key1, gid_base;   // lattice nodes, Philox key (seed), global id of env 0
+    float pitch;
+    int *episode;
+    float *act_out;                 // rand_act: optional record of the actions drawn, [T][E][N][2]
+    int lds_tail;                   // byte offset of the bookkeeping regions behind the bucket tables
 };
 
+// @phase h_nbr_list
 // (d, j) as ONE unsigned key whose integer order is the lexicographic order of the pair:
 // high word = order-preserving image of the float d, low word = j.
 __device__ __forceinline__ unsigned long long nbr_key(float d, int j)
@@ -111,12 +124,14 @@ __device__ __forceinline__ void nbr_insert(unsigned long long (&list)[K + 1], un
     }
 }
 
+// @phase h_nan_to_num
 __device__ __forceinline__ float nan_to_num_f32(float x)   // np.nan_to_num, drone_env.py:287-288
 {
     if (x != x) return 0.0f;
     return fminf(fmaxf(x, -3.402823466e+38f), 3.402823466e+38f);
 }
 
+// @phase h_stores
 // Output stores.  The outputs of a step are never re-read by the launch that writes them, so they are
 // written with the non-temporal (streaming) policy: lines drain to memory while the kernel runs instead
 // of sitting dirty in the XCD L2 until the end-of-kernel write-back.
@@ -133,6 +148,7 @@ __device__ __forceinline__ void st_out2(float *p, float x, float y)
     st_out(reinterpret_cast<f32x2 *>(p), v);
 }
 
+// @phase h_copy_out
 // Cooperative copy of `n` 4-byte words from a wave's LDS staging area to global memory: 16 bytes per
 // lane when the destination is 16-byte aligned (full 128-B lines, 1 KiB per wave-instruction),
 // 4 bytes per lane otherwise.
@@ -149,6 +165,59 @@ __device__ __forceinline__ void wave_copy_out(unsigned *__restrict__ dst, const 
     }
 }
 
+// @phase h_reduce
+// ---- fixed-order reductions of one float per lane (episode bookkeeping: sum of the step's rewards per env)
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_or_zero(float v)   // v of the lane CTRL selects, 0 where there is none / masked
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, true));
+}
+
+// Two sums over all 64 lanes for the price of one tree: the wave's halves are exchanged (v_permlane32_swap: lanes
+// 32-63 of `a` <-> lanes 0-31 of `b`) so that lanes 0-31 carry a[l] + a[l+32] and lanes 32-63 carry b[l-32] + b[l];
+// one DPP tree over the 32-lane halves (row_shr 1,2,3 -> quads, row_shr 4 / 8 -> rows, row_bcast 15 -> half) then
+// leaves sum(a) in lane 31 and sum(b) in lane 63.  The order of the additions is fixed: bit-reproducible.
+// (Tried on the matrix pipe instead -- two chained v_mfma_f32_16x16x4_f32 with B = ones per sum: +0.3 us per launch.)
+__device__ __forceinline__ float2 wave_sum64_pair(float a, float b)
+{
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    const float v = a + b;
+    float t = v + dpp_or_zero<0x111, 0xf, 0xf>(v);
+    t += dpp_or_zero<0x112, 0xf, 0xf>(v);
+    t += dpp_or_zero<0x113, 0xf, 0xf>(v);
+    t += dpp_or_zero<0x114, 0xf, 0xe>(t);
+    t += dpp_or_zero<0x118, 0xf, 0xc>(t);
+    t += dpp_or_zero<0x142, 0xa, 0xf>(t);
+    return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 31)),
+                       __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63)));
+}
+
+// sum over the n consecutive lanes of a segment (an env slot of a packed wave); valid in the segment's first lane
+// (`idx` = position inside the segment).  Fixed tree over lane offsets 1, 2, 4, ...: bit-reproducible.
+__device__ __forceinline__ float segment_sum(float v, int idx, int n)
+{
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const float o = __shfl_down(v, off, kWave);
+        v += (idx + off < n) ? o : 0.0f;
+    }
+    return v;
+}
+
+// RandomAgent.forward (SAC_agents.py:9-22): clip(-1 + 2 rand, -1, 1) on the 2^24-point grid of [-1, 1)
+__device__ __forceinline__ float unit_action(uint32_t w) { return fmaf((float)(w >> 8), 1.1920928955078125e-07f, -1.0f); }
+
+__device__ __forceinline__ uint32_t philox4x32_10_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                        uint32_t k0, uint32_t k1)
+{
+    uint32_t o[4];
+    philox4x32_10(c0, c1, c2, c3, k0, k1, o);
+    return o[0];
+}
+constexpr uint32_t kRandActKey = 0x52414E44u;   // "RAND": separates the action stream from the reset stream
+
+// @phase h_misc
 // Workgroup geometries
 //   kPacked  : N <= 64.  256 threads = 4 independent waves; each wave holds floor(64/N) whole envs and
 //              touches only its own LDS, so all synchronisation is wave-local (no s_barrier).
@@ -177,7 +246,10 @@ __device__ __forceinline__ void group_sync()
     }
 }
 
-template <int K, bool FAR, int MODE, int GEO>
+// EPI = true adds the episode bookkeeping of the *_ex entry points (DroneEpisodeCtl): per-env running sums, in-kernel
+// reset of finished envs, in-kernel random actions.  EPI = false is the plain step / observe / rollout: none of that
+// code exists in it.
+template <int K, bool FAR, int MODE, int GEO, bool EPI>
 __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::kMinWavesPerSimd) drone_kernel(
     // The first 8 dwords of the kernel arguments are preloaded into SGPRs at wave launch (Makefile:
     // -amdgpu-kernarg-preload-count=8; only leading scalar arguments qualify, not the struct): exactly what a
@@ -185,7 +257,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // (-0.2 us per launch at C3).  They override the same-named fields of `rest`.
     float *pos, const float *vel_or_act, int P, int epb, int E, int n_agents, const KArgs rest)
 {
+    // @phase setup
     KArgs a = rest;
+    // EPI: which parts of DroneEpisodeCtl are in use travels in the high half of the preloaded `epb` argument
+    // (bit 16 records, bit 17 auto-reset, bit 18 random actions), so that the branches that depend on it never wait
+    // for the kernel-argument fetch ahead of the first pos / act loads
+    const int epi_flags = EPI ? (epb >> 16) : 0;
+    if (EPI) epb &= 0xffff;
     a.pos = pos; a.P = P; a.epb = epb; a.E = E; a.N = n_agents;
     if (MODE == kObserve) a.vel = const_cast<float *>(vel_or_act); else a.act = vel_or_act;
     constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
@@ -220,15 +298,39 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     }
     const size_t wga0 = (size_t)env0 * N + (WL ? 0 : wave * kWave);
     const int env = env0 + (WL ? slot - wave * a.P : 0);
-    bool valid = (int)lane < nval;
     const bool masked = MODE == kObserve && a.mask != nullptr;
-    if (masked && valid) valid = a.mask[env] != 0;
+    bool valid;
+    if (SYM) {
+        // one env per wave and waves never synchronise with each other: a wave without an env (ragged last workgroup,
+        // masked-out env) simply leaves, and in every other wave all 64 lanes are agents -- no lane masking anywhere
+        // below, which also lets the scheduler move code across what would otherwise be exec-mask boundaries
+        if (nval == 0) return;
+        if (masked && a.mask[env] == 0) return;
+        valid = true;
+    } else {
+        valid = (int)lane < nval;
+        if (masked && valid) valid = a.mask[env] != 0;
+    }
     const size_t step_agents = (size_t)a.E * N;              // rollout: per-step output stride
 
+    // @phase loads
     // ---- longest-latency loads first: this agent's state (HBM), then the shared constants (L2)
     float xi = 0.f, yi = 0.f, vxi = 0.f, vyi = 0.f;
     float2 u0 = make_float2(0.f, 0.f);
     int tcur = 0;
+    // episode bookkeeping (dronesim_*_ex): the running sums of an env's DroneEpisodeAcc record live in the registers
+    // of its agent-0 lane for the whole launch; `epi` = resets the env has seen (stream id of reset and actions)
+    static_assert(!(EPI && MODE == kObserve), "observe has no episode bookkeeping");
+    const bool has_acc = EPI && (epi_flags & 1) != 0;
+    const bool auto_reset = EPI && (epi_flags & 2) != 0;
+    const bool rand_act = EPI && MODE == kRollout && (epi_flags & 4) != 0;
+    // the 32 hot bytes of the env's record live in registers for the whole launch, split over two lanes so that one
+    // load and one store instruction move them: agent 0 holds (ep_return, ep_true_return) as two doubles, agent 1
+    // holds (ep_collisions, ep_len, episodes, reserved) as four ints
+    uint4 accw = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t epi = 0u;
+    uint32_t rnd[4] = {0u, 0u, 0u, 0u};                      // rand_act: the Philox block of steps (t & ~1, t | 1)
+    const uint32_t gid = a.gid_base + (uint32_t)env;         // global env id (independent of the sharding)
     float xFx = 0.f, xFy = 0.f, dhat = 1.f, delta_i = 0.f, li = 0.f;
     // base addresses of the first loads, computed on the scalar unit before the branch
     const float2 *pos_in = reinterpret_cast<const float2 *>(a.pos) + wga0;
@@ -249,13 +351,24 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             const float2 v = vel_in[lane];
             vxi = v.x; vyi = v.y;
         } else {
-            if (BLOCKGEO) {
+            if (rand_act) {
+                // no action pool: the first action is drawn below, once t and the episode counter have arrived
+            } else if (BLOCKGEO) {
                 u0 = vel_in[lane];
             } else {
                 const f32x2 ul = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(vel_in) + lane);
                 u0 = make_float2(ul.x, ul.y);
             }
-            if (agent == 0) tcur = a.t[env];
+            if (rand_act) {                                  // every lane follows its env's counters
+                tcur = a.t[env];
+                epi = (uint32_t)a.episode[env];
+            } else if (agent == 0) {
+                tcur = a.t[env];
+            }
+#if !defined(DRONESIM_ABL_NOACCIO)
+            if (has_acc && agent < 2)
+                accw = *reinterpret_cast<const uint4 *>(a.acc + 8 * (size_t)env + 2 * agent);
+#endif
         }
         const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
         if (a.uniform) {
@@ -269,6 +382,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         xFx = g.x; xFy = g.y;
     }
 
+    // @phase lds_setup
     // ---- LDS carve-up (all region sizes multiples of 16 bytes); wave-local geometries give every wave
     //      its own copy of the (Delta_j, l_j) table so that no cross-wave barrier is ever needed
     // positions of one env slot: S0[m] = dup[m] and S1[m + 1] = dup[m], dup = x_0..x_{N-1}, x_0..x_{N-1}
@@ -291,6 +405,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     const int W = BLOCKGEO ? nwaves : 1;
     const bool use_bucket = !FAR && !SYM && (BLOCKGEO || a.bucket != 0);                   // launch-uniform
     unsigned long long *sbt = sbt_all + (size_t)slot * (2 * kCells) * W;                   // this lane's env
+    // tail (episode bookkeeping): per-wave partial reward sums [nwaves][2], then the lattice-sampling scratch of the
+    // in-kernel reset [epb][N] x (settled node, proposal)
+    float *spart = reinterpret_cast<float *>(smem + a.lds_tail);
+    int2 *ssamp = reinterpret_cast<int2 *>(spart + 2 * ((nwaves + 1) & ~1));
 
     // (Delta_j, l_j) of a partner: kernel-argument scalars when all agents share them -- except in the fused
     // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
@@ -330,13 +448,29 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     unsigned long long cand = 0ull;
     float refx = __builtin_nanf(""), refy = refx;            // NaN = no list yet
 
+    // @phase integrate
     for (int step = 0; step < nsteps; ++step) {
         const size_t so = (MODE == kRollout) ? (size_t)step * step_agents : 0;   // output offset (agents)
         const float *velsrc = (MODE == kObserve) ? a.vel : a.act + 2 * so;       // v of other agents
+        if (rand_act) {
+            // RandomAgent.forward (SAC_agents.py:9-22) drawn in place: one Philox block serves the steps t and t + 1
+            // of an env (words 0,1 / 2,3); it is recomputed when t is even or the block is not the env's current one
+            const bool need = valid && ((tcur & 1) == 0 || step == 0);
+            if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+                uint32_t fresh[4];
+                philox4x32_10((uint32_t)agent, gid, (uint32_t)tcur >> 1, epi, a.key0 ^ kRandActKey, a.key1, fresh);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) rnd[w] = need ? fresh[w] : rnd[w];
+            }
+            const bool odd = (tcur & 1) != 0;
+            u0 = make_float2(unit_action(odd ? rnd[2] : rnd[0]), unit_action(odd ? rnd[3] : rnd[1]));
+            if (valid && a.act_out != nullptr)
+                st_out2(a.act_out + 2 * (so + wga0 + lane), u0.x, u0.y);
+        }
         if (valid) {
             if (MODE != kObserve) {
                 const float2 u = u0;
-                if (MODE == kRollout && step + 1 < nsteps)    // prefetch the next step's action under this step's work
+                if (MODE == kRollout && !rand_act && step + 1 < nsteps)   // prefetch the next step's action under this step's work
                     u0 = (reinterpret_cast<const float2 *>(a.act) + so + step_agents + wga0)[lane];
                 xi = fmaf(a.dt, u.x, xi);                     // drone_env.py:235
                 yi = fmaf(a.dt, u.y, yi);
@@ -351,6 +485,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
             }
         }
+        // @phase filter_generic
         // ---- generic bucket filter, part 1: every agent ORs its bit into the mask of its x cell and of its y cell
         int bcx = 0, bcy = 0;
         if (use_bucket) {
@@ -370,6 +505,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             group_sync<WL>();
         }
 
+        // @phase pass2_init
         float zrx[K + 1], zry[K + 1];
         int nbv[K + 1];
         float s_all = 0.f, s_msk = 0.f;
@@ -382,6 +518,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         list[0] = nbr_key(dii, agent);
         int in_range = ((dii <= delta_i) ? 1 : 0) - 1;        // :346 (N_delta[i,i] uses Delta_i), minus itself
 
+        // @phase pass2_visit
         // pass 2 body: the pair (this agent, partner at index jdup of the doubled position array)
         auto visit = [&](int jdup) {
             const float2 pj = spos_env[jdup];
@@ -404,6 +541,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             nbr_insert<K>(list, nbr_key(d, j));                               // :338
         };
 
+        // @phase filter_generic2
         if (valid && use_bucket) {
             // ---- generic bucket filter, part 2.  Cells are at least reach_max wide, so every partner inside this
             // agent's radius sits in its cell or a neighbouring one on BOTH axes (cell numbers are hashed mod 64:
@@ -474,6 +612,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
             }
         }
+        // @phase filter_scan
         if (valid && !use_bucket) {
             const int rmax = N - 1;
             for (int r0 = 1; r0 <= rmax; r0 += 64) {
@@ -494,6 +633,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         near = cand;
                     }
                     if (rebuild) {
+                    // @phase filter_sym_bucket
                     // (a) bucket filter: cells of width >= the list radius along x and along y; a partner can
                     //     only be inside the radius if it sits in this agent's cell or a neighbouring one on
                     //     BOTH axes.  Each lane ORs its lane bit into the mask of its x cell and of its y cell
@@ -522,6 +662,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                             if (fmaf(dy, dy, dx * dx) < thr_list) hits |= 1ull << j;
                         }
                     } else {
+                    // @phase filter_sym_crowded
                     // (c) crowded env: every unordered pair once -- lane i tests partners i+1..i+32 and the
                     //     verdict reaches the other end as a rotated ballot.  The doubled / shifted copies of
                     //     the positions that those windows read are made here, on the rare path only.
@@ -587,6 +728,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         }
                     }
                 }
+                // @phase pass2_walk
                 // ---- pass 2: every lane walks its own surviving partners
 #if defined(DRONESIM_ABLATE_PASS2)
                 s_all += (float)__builtin_popcountll(near); near = 0ull;
@@ -598,14 +740,18 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
             }
         }
+        // @phase epilogue_rewards_z
+        float r_out = 0.0f, tr_out = 0.0f;                    // this lane's rewards (episode bookkeeping)
         if (valid) {
             TRACE_MARK(3);
             // rewards (:276, :287-288)
             const float gx = xFx - xi, gy = xFy - yi;
             const float err2 = fmaf(gy, gy, gx * gx);
             const float to_goal = a.q * err2;
-            if (a.reward) st_out(a.reward + so + wga0 + lane, -nan_to_num_f32(fmaf(a.b, s_msk, to_goal)));
-            if (a.true_reward) st_out(a.true_reward + so + wga0 + lane, -nan_to_num_f32(fmaf(a.b, s_all, to_goal)));
+            r_out = -nan_to_num_f32(fmaf(a.b, s_msk, to_goal));
+            tr_out = -nan_to_num_f32(fmaf(a.b, s_all, to_goal));
+            if (a.reward) st_out(a.reward + so + wga0 + lane, r_out);
+            if (a.true_reward) st_out(a.true_reward + so + wga0 + lane, tr_out);
 
             // localized state rows + neighbour list (:344-397)
             const float zx = xi - xFx, zy = yi - xFy;                         // :357
@@ -641,7 +787,15 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                             row[2] = vxi; row[3] = vyi; row[4] = li;          // :355
                         } else if (have[kth]) {                               // :367 / :385
                             const unsigned j = (unsigned)list[kth];
-                            const float2 vj = reinterpret_cast<const float2 *>(velsrc)[(size_t)env * N + j];
+                            float2 vj;
+                            if (rand_act) {                            // counter-based stream: any lane can
+                                uint32_t o[4];                                // restate any agent's action
+                                philox4x32_10(j, gid, (uint32_t)(tcur >> 1), epi, a.key0 ^ kRandActKey, a.key1, o);
+                                vj = (tcur & 1) ? make_float2(unit_action(o[2]), unit_action(o[3]))
+                                                : make_float2(unit_action(o[0]), unit_action(o[1]));
+                            } else {
+                                vj = reinterpret_cast<const float2 *>(velsrc)[(size_t)env * N + j];
+                            }
                             row[2] = vj.x; row[3] = vj.y; row[4] = uni_args ? a.radius_u : sconst[j].y;
                         } else {
                             row[2] = row[3] = row[4] = __builtin_nanf("");
@@ -650,6 +804,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
             }
 
+            // @phase epilogue_state_done
             if (MODE != kObserve) {
                 if (MODE != kRollout || step == nsteps - 1) {                 // final state only
                     st_out2(a.pos + 2 * wga0 + 2 * lane, xi, yi);
@@ -659,6 +814,15 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             }
             if (ncoll) atomicAdd(&sred[2 * slot], ncoll);
         }
+        // episode bookkeeping: sum of this step's rewards per env, fixed order (bit-reproducible).  Workgroup-per-env
+        // geometries leave one partial per wave in LDS ahead of the barrier below; wave-local geometries reduce after
+        // their output stores have been issued (the reduction is a dependent chain: nothing should queue behind it)
+        float r_env = 0.0f, tr_env = 0.0f;                    // valid in the env's agent-0 lane
+        if (!WL && has_acc) {
+            const float2 sm = wave_sum64_pair(r_out, tr_out);
+            if (lane == 0) { spart[2 * wave] = sm.x; spart[2 * wave + 1] = sm.y; }
+        }
+        // @phase stage_and_copy_out
 #if defined(DRONESIM_ABLATE_ZOUT)
         if (valid) { float acc = 0.f;
 #pragma unroll
@@ -677,6 +841,16 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         }
         TRACE_MARK(4);
         group_sync<WL>();
+#if !defined(DRONESIM_ABL_NOSUM)
+        if (WL && has_acc) {
+            if (SYM) {
+                const float2 sm = wave_sum64_pair(r_out, tr_out);
+                r_env = sm.x; tr_env = sm.y;
+            } else {
+                r_env = segment_sum(r_out, agent, N); tr_env = segment_sum(tr_out, agent, N);
+            }
+        }
+#endif
 #if defined(DRONESIM_ABLATE_ZOUT)
         if (false) {
 #else
@@ -686,6 +860,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             unsigned *gn = reinterpret_cast<unsigned *>(a.nbr_idx) + (so + wga0) * kNRow;
             if (SYM) {
                 // full wave of one env, 16-byte aligned rows (checked on the host): fixed-shape copy, no loops
+                // (a branch-free variant -- surplus lanes of a ragged last round repeating a live lane's 16 bytes, so
+                // that the kernel's tail is one basic block -- was 0.14 us slower per launch: the stores got wider)
                 constexpr int nz = kWave * kZRow, nn = kWave * kNRow;          // words
 #pragma unroll
                 for (int o = 0; o < nz; o += 4 * kWave)
@@ -700,19 +876,168 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 wave_copy_out(gn, stage_n, nval * kNRow, lane);
             }
         }
-        if (valid && agent == 0) {
-            const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
-            if (a.n_coll) a.n_coll[eo] = sred[2 * slot];
-            if (MODE != kObserve) {
-                a.done[eo] = (uint8_t)((sred[2 * slot + 1] == 0) || (tcur >= a.max_steps - 1));   // :251
-                tcur += 1;                                                                        // :256
+        // @phase env_outputs
+        bool fin_env = false;                                 // agent 0: this env's episode ended with this step
+        if (valid && (agent == 0 || (has_acc && agent == 1))) {
+            const int2 red = *reinterpret_cast<const int2 *>(sred + 2 * slot);   // (collisions, someone outside the goal disk)
+            const int coll_env = red.x;
+            if (agent == 0) {
+                const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
+                if (a.n_coll) a.n_coll[eo] = coll_env;
+                bool fin = false;
+                if (MODE != kObserve) {
+                    fin = (red.y == 0) || (tcur >= a.max_steps - 1);                              // :251
+                    a.done[eo] = (uint8_t)fin;
+                    fin_env = fin;
+                }
+                if (has_acc) {                                    // train_problem.py:98-99, every step
+                    if (!WL) {
+                        for (int w = 0; w < nwaves; ++w) { r_env += spart[2 * w]; tr_env += spart[2 * w + 1]; }
+                    }
+                    const double nr = __builtin_bit_cast(double, make_uint2(accw.x, accw.y)) + (double)r_env;
+                    const double ntr = __builtin_bit_cast(double, make_uint2(accw.z, accw.w)) + (double)tr_env;
+                    const uint2 w0 = __builtin_bit_cast(uint2, nr), w1 = __builtin_bit_cast(uint2, ntr);
+                    accw = make_uint4(w0.x, w0.y, w1.x, w1.y);
+                }
+                *reinterpret_cast<int2 *>(sred + 2 * slot) = make_int2(0, (auto_reset && fin) ? 1 : 0);   // under auto_reset: "re-sample this env"
+            } else {                                              // train_problem.py:100 and t_iter, every step
+                accw.x += (unsigned)coll_env; accw.y += 1u;
             }
-            sred[2 * slot] = 0;
-            sred[2 * slot + 1] = 0;
+        }
+        if (MODE != kObserve && (rand_act || agent == 0)) tcur += 1;                              // :256
+#if defined(DRONESIM_ABL_NOCOLD)
+        if (false) {
+#else
+        if (EPI && auto_reset) {
+#endif
+            // @phase auto_reset
+            // ---- in-kernel reset (drone_env.py:98-102 after the `while not finished` loop, train_problem.py:132).
+            // Every lane learns whether its env finished.  Finished envs retire their episode record, draw N distinct
+            // lattice nodes exactly as reset_kernel does (same Philox stream, same acceptance rule) and are observed
+            // again (drone_env.py:208-210) by a plain all-partner pass: this runs once per episode and env, so it is
+            // written for size, not speed; its arithmetic is the hot path's own `visit`, so z / Ni are bit-identical
+            // to what dronesim_reset + dronesim_observe produce.
+            bool rs, any_rs;
+            if (SYM) {                                        // one env per wave: agent 0 is lane 0, its verdict is the wave's
+                any_rs = __builtin_amdgcn_readfirstlane((int)fin_env) != 0;
+                rs = any_rs;
+            } else {
+                group_sync<WL>();
+                rs = valid && sred[2 * slot + 1] != 0;
+                any_rs = WL ? (__builtin_amdgcn_ballot_w64(rs) != 0ull) : (__syncthreads_or(rs ? 1 : 0) != 0);
+            }
+            if (any_rs) {
+                if (!rand_act && rs)                          // the episode counter is only needed here: read it now (past
+                    epi = (uint32_t)__builtin_nontemporal_load(a.episode + env);   // L1: an earlier reset of this launch wrote it)
+                if (rs && agent == 0) {
+                    sred[2 * slot + 1] = 0;
+                    a.episode[env] = (int)(epi + 1u);
+                }
+                if (rs && has_acc && agent < 2) {                 // retire the finished episode (train_problem.py:118-121)
+                    double *tot = a.acc + 8 * (size_t)env + 4 + 2 * agent;        // agent 0: done_return, done_true_return
+                    if (agent == 0) {                                             // agent 1: done_collisions, done_len
+                        const double2 dn = *reinterpret_cast<const double2 *>(tot);
+                        *reinterpret_cast<double2 *>(tot) =
+                            make_double2(dn.x + __builtin_bit_cast(double, make_uint2(accw.x, accw.y)),
+                                         dn.y + __builtin_bit_cast(double, make_uint2(accw.z, accw.w)));
+                        accw = make_uint4(0u, 0u, 0u, 0u);
+                    } else {
+                        const longlong2 dl = *reinterpret_cast<const longlong2 *>(tot);
+                        *reinterpret_cast<longlong2 *>(tot) = make_longlong2(dl.x + (int)accw.x, dl.y + (int)accw.y);
+                        accw = make_uint4(0u, 0u, accw.z + 1u, accw.w);           // episodes += 1
+                    }
+                }
+                int2 *mine = ssamp + (size_t)slot * N;
+                int node = -1;
+                uint32_t round = 0;
+                bool more;
+                do {
+                    int prop = -1;
+                    if (rs) {
+                        if (node < 0)
+                            prop = (int)__umulhi(philox4x32_10_word0((uint32_t)agent, round, gid, epi, a.key0, a.key1), a.lat_M);
+                        mine[agent] = make_int2(node, prop);
+                    }
+                    group_sync<WL>();
+                    if (rs && node < 0) {
+                        bool clash = false;
+#pragma nounroll
+                        for (int j = 0; j < N; ++j) {
+                            const int2 o = mine[j];
+                            const bool held = o.x >= 0 && o.x == prop;                // held since an earlier round
+                            const bool lower = o.x < 0 && j < agent && o.y == prop;   // lower index wins the round
+                            clash = clash || held || lower;
+                        }
+                        if (!clash) node = prop;
+                    }
+                    const bool left = rs && node < 0;
+                    more = WL ? (__builtin_amdgcn_ballot_w64(left) != 0ull) : (__syncthreads_or(left ? 1 : 0) != 0);
+                    if (WL) group_sync<true>();                   // this round's reads before the next round's writes
+                    ++round;
+                } while (more && round < (1u << 20));
+                if (rs) {
+                    const int idx = node / a.div_y, jdx = node - idx * a.div_y;
+                    xi = (float)idx * a.pitch; yi = (float)jdx * a.pitch;         // drone_env.py:196-205
+                    vxi = 0.f; vyi = 0.f;                                         // :189
+                    tcur = 0;                                                     // :100
+                    epi += 1u;
+                    __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): the counter store above has landed
+                    if (CACHED) refx = __builtin_nanf("");                        // the candidate list is stale
+                    spos_env[agent] = make_float2(xi, yi);
+                }
+                group_sync<WL>();
+                __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this wave's earlier z / Ni / state stores
+                if (rs) {                                         //           have landed before they are overwritten
+#pragma unroll
+                    for (int s2 = 0; s2 <= K; ++s2) list[s2] = ~0ull;
+                    list[0] = nbr_key(dii, agent);
+                    in_range = ((dii <= delta_i) ? 1 : 0) - 1;
+#pragma nounroll
+                    for (int j = 0; j < N; ++j) {                 // ascending order, like every other path
+                        if (j == agent) continue;
+                        if (!FAR) {
+                            const float2 pj = spos_env[j];
+                            const float dx = xi - pj.x, dy = yi - pj.y;
+                            if (!(fmaf(dy, dy, dx * dx) < thr)) continue;
+                        }
+                        visit(j);
+                    }
+                    const float zx = xi - xFx, zy = yi - xFy;
+                    const float gsc = __builtin_amdgcn_rsqf(fmaf(zy, zy, zx * zx)) * delta_i * a.ghost_factor;
+                    float *zr = a.z + (so + wga0 + lane) * (size_t)((K + 1) * zc);
+                    int *nb = a.nbr_idx + (so + wga0 + lane) * (size_t)(K + 1);
+#pragma unroll
+                    for (int kth = 0; kth <= K; ++kth) {
+                        const unsigned j = (unsigned)list[kth];
+                        const bool hv = kth == 0 || j < (unsigned)N;
+                        const bool real = kth == 0 || (kth <= in_range && hv);
+                        float rx = kth == 0 ? zx : zx * gsc, ry = kth == 0 ? zy : zy * gsc;
+                        if (kth > 0 && real) {
+                            const float2 pj = spos_env[j];
+                            rx = pj.x - xi; ry = pj.y - yi;
+                        }
+                        nb[kth] = kth == 0 ? agent : (real ? (int)j : -1);
+                        float *row = zr + kth * zc;
+                        row[0] = rx; row[1] = ry;
+                        if (zc == 5) {
+                            if (kth == 0) { row[2] = 0.f; row[3] = 0.f; row[4] = li; }
+                            else if (hv) { row[2] = 0.f; row[3] = 0.f; row[4] = uni_args ? a.radius_u : sconst[j].y; }
+                            else { row[2] = row[3] = row[4] = __builtin_nanf(""); }
+                        }
+                    }
+                    if (MODE != kRollout || step == nsteps - 1) {
+                        st_out2(a.pos + 2 * wga0 + 2 * lane, xi, yi);
+                        st_out2(a.vel + 2 * wga0 + 2 * lane, 0.f, 0.f);
+                    }
+                }
+            }
         }
         if (MODE == kRollout) group_sync<WL>();               // staging / sred reuse by the next step
     }
     if (MODE != kObserve && valid && agent == 0) a.t[env] = tcur;
+#if !defined(DRONESIM_ABL_NOACCIO)
+    if (has_acc && valid && agent < 2) *reinterpret_cast<uint4 *>(a.acc + 8 * (size_t)env + 2 * agent) = accw;
+#endif
     TRACE_MARK(5);
 #if defined(DRONESIM_TRACE)
     __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): all stores acknowledged
@@ -732,20 +1057,6 @@ namespace {
 // reset: N distinct lattice nodes per env by parallel rejection on a Philox4x32-10 stream
 // (restated integer-exactly on the CPU in oracle/drone_oracle.c:oracle_reset).
 
-__device__ __forceinline__ uint32_t philox4x32_10_word0(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
-                                                        uint32_t k0, uint32_t k1)
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
-
 struct RArgs {
     int N, E, P, epb, div_y;
     uint32_t M, key0, key1;
@@ -754,6 +1065,7 @@ struct RArgs {
     const uint8_t *mask;
     float *pos, *vel;
     int *t, *episode, *node_out;
+    double *acc;                    // DroneEpisodeAcc[E] (8 x 8 bytes per env) or nullptr: retire the episode in progress
 };
 
 __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
@@ -817,6 +1129,17 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
         if (agent == 0) {
             a.t[env] = 0;                                                // drone_env.py:100
             a.episode[env] = (int)(epi + 1u);
+            if (a.acc != nullptr) {                                      // train_problem.py:118-121: log, then reset
+                double *rec = a.acc + 8 * (size_t)env;
+                int *reci = reinterpret_cast<int *>(rec);
+                if (reci[5] > 0) {                                       // ep_len: an episode was in progress
+                    rec[4] += rec[0]; rec[5] += rec[1];
+                    reinterpret_cast<long long *>(rec)[6] += reci[4];
+                    reinterpret_cast<long long *>(rec)[7] += reci[5];
+                    reci[6] += 1;
+                    rec[0] = 0.0; rec[1] = 0.0; reci[4] = 0; reci[5] = 0;
+                }
+            }
         }
     }
 }
@@ -1000,6 +1323,33 @@ __global__ void __launch_bounds__(256) stats_kernel(const float *__restrict__ re
     }
 }
 
+// Sum of the E episode records of a rank -> out[8] (include/dronesim.h).  ONE workgroup: thread i adds the records
+// i, i + 1024, ... in order, then a fixed LDS tree: the summation order does not depend on anything but E.
+__global__ void __launch_bounds__(1024) episode_reduce_kernel(const double *__restrict__ acc, int E, double *__restrict__ out)
+{
+    __shared__ double sh[8][1024];
+    const int tid = threadIdx.x;
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = tid; e < E; e += 1024) {
+        const double *rec = acc + 8 * (size_t)e;
+        const int *reci = reinterpret_cast<const int *>(rec);
+        const long long *recl = reinterpret_cast<const long long *>(rec);
+        v[0] += rec[4]; v[1] += rec[5]; v[2] += (double)recl[6]; v[3] += (double)recl[7]; v[4] += (double)reci[6];
+        v[5] += rec[0]; v[6] += rec[1]; v[7] += (double)reci[5];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[k][tid] = v[k];
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if (tid < w) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sh[k][tid] += sh[k][tid + w];
+        }
+        __syncthreads();
+    }
+    if (tid < 8) out[tid] = sh[tid][0];
+}
+
 // ---------------------------------------------------------------------------------------
 thread_local char g_err[256] = "";
 #if defined(DRONESIM_TRACE)
@@ -1063,6 +1413,13 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k)
     return b;
 }
 
+// bookkeeping regions behind the bucket tables: [nwaves rounded to even][2] floats + [epb][N] int2
+size_t drone_lds_tail_bytes(const Geometry &g, int N)
+{
+    const size_t nwaves = (size_t)g.threads / kWave;
+    return sizeof(float) * 2 * ((nwaves + 1) & ~(size_t)1) + sizeof(int2) * (size_t)g.epb * N;
+}
+
 int check_params(const DroneParams *p, int E)
 {
     if (!p) return fail(DRONESIM_EINVAL, "params is NULL");
@@ -1081,81 +1438,123 @@ int check_params(const DroneParams *p, int E)
 
 #if DRONESIM_PART != 0
 // more than 64 KiB of dynamic LDS (envs of several hundred agents) has to be opted into once per kernel
-template <int K, bool FAR, int MODE, int GEO>
-void launch_one(const KArgs &a, const Geometry &g, hipStream_t s)
+template <int K, bool FAR, int MODE, int GEO, bool EPI>
+hipError_t launch_one(const KArgs &a, const Geometry &g, hipStream_t s)
 {
-    static bool big_lds = false;
-    if (g.lds > 48 * 1024 && !big_lds) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(drone_kernel<K, FAR, MODE, GEO>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        big_lds = true;
+    if (g.lds > 48 * 1024) {
+        // once per (kernel, device): remembered in a per-instantiation bit mask of device ordinals under a mutex
+        static std::mutex mu;
+        static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};   // device ordinals 0..255
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 255) dev = 0;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!(opted[dev >> 6] >> (dev & 63) & 1ull)) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(drone_kernel<K, FAR, MODE, GEO, EPI>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;   // reported by launch() through dronesim_last_error()
+            opted[dev >> 6] |= 1ull << (dev & 63);
+        }
     }
-    hipLaunchKernelGGL((drone_kernel<K, FAR, MODE, GEO>), dim3(g.blocks), dim3(g.threads), g.lds, s,
-                       a.pos, MODE == kObserve ? static_cast<const float *>(a.vel) : a.act, a.P, a.epb, a.E, a.N, a);
+    hipLaunchKernelGGL((drone_kernel<K, FAR, MODE, GEO, EPI>), dim3(g.blocks), dim3(g.threads), g.lds, s,
+                       a.pos, MODE == kObserve ? static_cast<const float *>(a.vel) : a.act, a.P,
+                       EPI ? (a.epb | ((a.acc != nullptr ? 1 : 0) | (a.auto_reset ? 2 : 0) | (a.rand_act ? 4 : 0)) << 16) : a.epb,
+                       a.E, a.N, a);
+    return hipSuccess;
 }
 
 template <int K, bool FAR, int GEO>
-void launch_mode(int mode, const KArgs &a, const Geometry &g, hipStream_t s)
+hipError_t launch_mode(int mode, const KArgs &a, const Geometry &g, hipStream_t s)
 {
+    bool epi = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;   // DroneEpisodeCtl in use
+#if defined(DRONESIM_DEBUG_HOOKS)
+    if (getenv("DRONESIM_FORCE_EPI")) epi = true;                         // developer ablation: bookkeeping kernel, all off
+#endif
     switch (mode) {
-    case kStep: launch_one<K, FAR, kStep, GEO>(a, g, s); break;
-    case kObserve: launch_one<K, FAR, kObserve, GEO>(a, g, s); break;
-    default: launch_one<K, FAR, kRollout, GEO>(a, g, s); break;
+    case kStep: return epi ? launch_one<K, FAR, kStep, GEO, true>(a, g, s) : launch_one<K, FAR, kStep, GEO, false>(a, g, s);
+    case kObserve: return launch_one<K, FAR, kObserve, GEO, false>(a, g, s);
+    default: return epi ? launch_one<K, FAR, kRollout, GEO, true>(a, g, s) : launch_one<K, FAR, kRollout, GEO, false>(a, g, s);
     }
 }
 
 template <int K>
-void launch_k(int mode, bool far, const KArgs &a, const Geometry &g, hipStream_t s)
+hipError_t launch_k(int mode, bool far, const KArgs &a, const Geometry &g, hipStream_t s)
 {
     switch (g.geo) {
-    case kSym64: launch_mode<K, false, kSym64>(mode, a, g, s); break;
+    case kSym64: return launch_mode<K, false, kSym64>(mode, a, g, s);
     case kPacked:
-        if (far) launch_mode<K, true, kPacked>(mode, a, g, s);
-        else launch_mode<K, false, kPacked>(mode, a, g, s);
-        break;
+        return far ? launch_mode<K, true, kPacked>(mode, a, g, s) : launch_mode<K, false, kPacked>(mode, a, g, s);
     case kBlock256:
-        if (far) launch_mode<K, true, kBlock256>(mode, a, g, s);
-        else launch_mode<K, false, kBlock256>(mode, a, g, s);
-        break;
+        return far ? launch_mode<K, true, kBlock256>(mode, a, g, s) : launch_mode<K, false, kBlock256>(mode, a, g, s);
     default:
-        if (far) launch_mode<K, true, kBlock1024>(mode, a, g, s);
-        else launch_mode<K, false, kBlock1024>(mode, a, g, s);
-        break;
+        return far ? launch_mode<K, true, kBlock1024>(mode, a, g, s) : launch_mode<K, false, kBlock1024>(mode, a, g, s);
     }
 }
 
 #endif   // DRONESIM_PART != 0
 }   // namespace
 
-#if DRONESIM_PART >= 1      // this part's two k values, called from part 0
+#if DRONESIM_PART >= 1      // this part's k value, called from part 0
 #define DRONESIM_PART_ENTRY2(n) dronesim_launch_part##n
 #define DRONESIM_PART_ENTRY(n) DRONESIM_PART_ENTRY2(n)
 extern "C" __attribute__((visibility("hidden")))
-void DRONESIM_PART_ENTRY(DRONESIM_PART)(int k, int mode, int far, const void *a, const void *g, void *s)
+int DRONESIM_PART_ENTRY(DRONESIM_PART)(int k, int mode, int far, const void *a, const void *g, void *s)
 {
-    constexpr int k0 = 2 * DRONESIM_PART - 1;
-    if (k == k0) launch_k<k0>(mode, far != 0, *static_cast<const KArgs *>(a), *static_cast<const Geometry *>(g), static_cast<hipStream_t>(s));
-    else launch_k<k0 + 1>(mode, far != 0, *static_cast<const KArgs *>(a), *static_cast<const Geometry *>(g), static_cast<hipStream_t>(s));
+    (void)k;                                          // part p holds k_closest = p
+    return (int)launch_k<DRONESIM_PART>(mode, far != 0, *static_cast<const KArgs *>(a), *static_cast<const Geometry *>(g), static_cast<hipStream_t>(s));
 }
 #endif
 
 #if DRONESIM_PART == 0
 extern "C" {
-void dronesim_launch_part1(int, int, int, const void *, const void *, void *);
-void dronesim_launch_part2(int, int, int, const void *, const void *, void *);
-void dronesim_launch_part3(int, int, int, const void *, const void *, void *);
-void dronesim_launch_part4(int, int, int, const void *, const void *, void *);
+int dronesim_launch_part1(int, int, int, const void *, const void *, void *);
+int dronesim_launch_part2(int, int, int, const void *, const void *, void *);
+int dronesim_launch_part3(int, int, int, const void *, const void *, void *);
+int dronesim_launch_part4(int, int, int, const void *, const void *, void *);
+int dronesim_launch_part5(int, int, int, const void *, const void *, void *);
+int dronesim_launch_part6(int, int, int, const void *, const void *, void *);
+int dronesim_launch_part7(int, int, int, const void *, const void *, void *);
+int dronesim_launch_part8(int, int, int, const void *, const void *, void *);
 }
 #endif
 
 #if DRONESIM_PART <= 0
 namespace {
 
+int reset_impl(const DroneParams *p, int div_x, int div_y, float pitch, uint64_t seed, int64_t env_base,
+               const uint8_t *mask, float *pos, float *vel, int32_t *t, int32_t *episode, int32_t *node_out,
+               double *acc, int E, void *stream);
+
+// DroneEpisodeCtl -> kernel arguments (include/dronesim.h)
+int apply_ctl(const DroneParams *p, const DroneEpisodeCtl *ctl, bool rand_act, KArgs &a)
+{
+    a.rand_act = rand_act ? 1 : 0;
+    if (!ctl) return DRONESIM_OK;
+    a.acc = reinterpret_cast<double *>(ctl->acc);
+    a.auto_reset = ctl->auto_reset != 0 ? 1 : 0;
+    if (a.auto_reset || rand_act) {
+        if (!ctl->episode) return fail(DRONESIM_EINVAL, "DroneEpisodeCtl.episode is NULL");
+        a.episode = ctl->episode;
+        a.key0 = (uint32_t)ctl->seed;
+        a.key1 = (uint32_t)(ctl->seed >> 32);
+        a.gid_base = (uint32_t)ctl->env_base;
+    }
+    if (a.auto_reset) {
+        if (ctl->div_x < 1 || ctl->div_y < 1) return fail(DRONESIM_EINVAL, "DroneEpisodeCtl: bad lattice size");
+        const uint64_t M = (uint64_t)ctl->div_x * (uint64_t)ctl->div_y;
+        if (M < (uint64_t)p->N) return fail(DRONESIM_EINVAL, "lattice has fewer nodes than agents (random.sample would raise)");
+        if (M > 0xFFFFFFFFull) return fail(DRONESIM_EUNSUPPORTED, "lattice larger than 2^32 nodes");
+        a.lat_M = (uint32_t)M; a.div_y = ctl->div_y; a.pitch = ctl->pitch;
+    }
+    return DRONESIM_OK;
+}
+
 int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
 {
     if (E == 0) return DRONESIM_OK;
     Geometry g = geometry(p->N, E);
     g.lds = drone_lds_bytes(g, p->N, p->k);
+    a.lds_tail = (int)g.lds;
+    g.lds += drone_lds_tail_bytes(g, p->N);
     if (g.lds > 160 * 1024) return fail(DRONESIM_EUNSUPPORTED, "n_agents x k_closest too large for the 160 KiB LDS tile");
     a.N = p->N; a.c = p->c; a.max_steps = p->max_steps; a.E = E;
     a.P = g.P; a.epb = g.epb;
@@ -1181,27 +1580,39 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
 #if DRONESIM_PART == 0
-    static_assert(DRONESIM_MAX_K == 8, "four parts of two k values");
-    switch ((p->k - 1) / 2) {
-    case 0: dronesim_launch_part1(p->k, mode, far, &a, &g, s); break;
-    case 1: dronesim_launch_part2(p->k, mode, far, &a, &g, s); break;
-    case 2: dronesim_launch_part3(p->k, mode, far, &a, &g, s); break;
-    case 3: dronesim_launch_part4(p->k, mode, far, &a, &g, s); break;
+    static_assert(DRONESIM_MAX_K == 8, "eight parts, one k value each");
+    int le = 0;
+    switch (p->k) {
+    case 1: le = dronesim_launch_part1(p->k, mode, far, &a, &g, s); break;
+    case 2: le = dronesim_launch_part2(p->k, mode, far, &a, &g, s); break;
+    case 3: le = dronesim_launch_part3(p->k, mode, far, &a, &g, s); break;
+    case 4: le = dronesim_launch_part4(p->k, mode, far, &a, &g, s); break;
+    case 5: le = dronesim_launch_part5(p->k, mode, far, &a, &g, s); break;
+    case 6: le = dronesim_launch_part6(p->k, mode, far, &a, &g, s); break;
+    case 7: le = dronesim_launch_part7(p->k, mode, far, &a, &g, s); break;
+    case 8: le = dronesim_launch_part8(p->k, mode, far, &a, &g, s); break;
     default: return fail(DRONESIM_EUNSUPPORTED, "k_closest > DRONESIM_MAX_K");
     }
 #else
+    int le = 0;
     switch (p->k) {
-    case 1: launch_k<1>(mode, far, a, g, s); break;
-    case 2: launch_k<2>(mode, far, a, g, s); break;
-    case 3: launch_k<3>(mode, far, a, g, s); break;
-    case 4: launch_k<4>(mode, far, a, g, s); break;
-    case 5: launch_k<5>(mode, far, a, g, s); break;
-    case 6: launch_k<6>(mode, far, a, g, s); break;
-    case 7: launch_k<7>(mode, far, a, g, s); break;
-    case 8: launch_k<8>(mode, far, a, g, s); break;
+    case 1: le = (int)launch_k<1>(mode, far, a, g, s); break;
+    case 2: le = (int)launch_k<2>(mode, far, a, g, s); break;
+    case 3: le = (int)launch_k<3>(mode, far, a, g, s); break;
+    case 4: le = (int)launch_k<4>(mode, far, a, g, s); break;
+    case 5: le = (int)launch_k<5>(mode, far, a, g, s); break;
+    case 6: le = (int)launch_k<6>(mode, far, a, g, s); break;
+    case 7: le = (int)launch_k<7>(mode, far, a, g, s); break;
+    case 8: le = (int)launch_k<8>(mode, far, a, g, s); break;
     default: return fail(DRONESIM_EUNSUPPORTED, "k_closest > DRONESIM_MAX_K");
     }
 #endif
+    if (le != 0) {
+        char msg[200];
+        snprintf(msg, sizeof(msg), "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for %zu bytes of LDS: %s",
+                 g.lds, hipGetErrorString(static_cast<hipError_t>(le)));
+        return fail(DRONESIM_ELAUNCH, msg);
+    }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
@@ -1211,18 +1622,26 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
 
 extern "C" {
 
-int dronesim_step(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
-                  float *reward, float *true_reward, float *z, int32_t *nbr_idx,
-                  int32_t *n_coll, uint8_t *done, int E, void *stream)
+int dronesim_step_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, float *pos, float *vel, int32_t *t,
+                     const float *act, float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                     int32_t *n_coll, uint8_t *done, int E, void *stream)
 {
-    const int rc = check_params(p, E);
+    int rc = check_params(p, E);
     if (rc) return rc;
     if (!pos || !vel || !t || !act || !z || !nbr_idx || !done)
         return fail(DRONESIM_EINVAL, "dronesim_step: required buffer is NULL");
     KArgs a{};
     a.pos = pos; a.vel = vel; a.t = t; a.act = act; a.reward = reward; a.true_reward = true_reward;
     a.z = z; a.nbr_idx = nbr_idx; a.n_coll = n_coll; a.done = done; a.T = 1;
+    if ((rc = apply_ctl(p, ctl, false, a)) != 0) return rc;
     return launch(kStep, p, a, E, stream);
+}
+
+int dronesim_step(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
+                  float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                  int32_t *n_coll, uint8_t *done, int E, void *stream)
+{
+    return dronesim_step_ex(p, nullptr, pos, vel, t, act, reward, true_reward, z, nbr_idx, n_coll, done, E, stream);
 }
 
 int dronesim_observe(const DroneParams *p, const float *pos, const float *vel,
@@ -1239,11 +1658,11 @@ int dronesim_observe(const DroneParams *p, const float *pos, const float *vel,
     return launch(kObserve, p, a, E, stream);
 }
 
-int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
-                     float *reward, float *true_reward, float *z, int32_t *nbr_idx,
-                     int32_t *n_coll, uint8_t *done, int E, int T, void *stream)
+int dronesim_rollout_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, float *pos, float *vel, int32_t *t,
+                        const float *act, float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                        int32_t *n_coll, uint8_t *done, int E, int T, void *stream)
 {
-    const int rc = check_params(p, E);
+    int rc = check_params(p, E);
     if (rc) return rc;
     if (T < 0) return fail(DRONESIM_EINVAL, "T < 0");
     if (!pos || !vel || !t || !act || !z || !nbr_idx || !done)
@@ -1253,6 +1672,34 @@ int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, c
     a.pos = pos; a.vel = vel; a.t = t; a.act = act; a.reward = reward; a.true_reward = true_reward;
     a.z = z; a.nbr_idx = nbr_idx; a.n_coll = n_coll; a.done = done; a.T = T;
     a.skin = 0.4f * (p->d_hat_max + 2.0f * p->radius_max);
+    if ((rc = apply_ctl(p, ctl, false, a)) != 0) return rc;
+    return launch(kRollout, p, a, E, stream);
+}
+
+int dronesim_rollout(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
+                     float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                     int32_t *n_coll, uint8_t *done, int E, int T, void *stream)
+{
+    return dronesim_rollout_ex(p, nullptr, pos, vel, t, act, reward, true_reward, z, nbr_idx, n_coll, done, E, T, stream);
+}
+
+int dronesim_rollout_random(const DroneParams *p, const DroneEpisodeCtl *ctl, float *pos, float *vel, int32_t *t,
+                            float *act_out, float *reward, float *true_reward, float *z, int32_t *nbr_idx,
+                            int32_t *n_coll, uint8_t *done, int E, int T, void *stream)
+{
+    int rc = check_params(p, E);
+    if (rc) return rc;
+    if (T < 0) return fail(DRONESIM_EINVAL, "T < 0");
+    if (!ctl || !ctl->episode) return fail(DRONESIM_EINVAL, "dronesim_rollout_random: ctl with seed / env_base / episode is required");
+    if (!pos || !vel || !t || !z || !nbr_idx || !done)
+        return fail(DRONESIM_EINVAL, "dronesim_rollout_random: required buffer is NULL");
+    if (T == 0) return DRONESIM_OK;
+    KArgs a{};
+    a.pos = pos; a.vel = vel; a.t = t; a.act = nullptr; a.reward = reward; a.true_reward = true_reward;
+    a.z = z; a.nbr_idx = nbr_idx; a.n_coll = n_coll; a.done = done; a.T = T;
+    a.skin = 0.4f * (p->d_hat_max + 2.0f * p->radius_max);
+    a.act_out = act_out;
+    if ((rc = apply_ctl(p, ctl, true, a)) != 0) return rc;
     return launch(kRollout, p, a, E, stream);
 }
 
@@ -1260,6 +1707,16 @@ int dronesim_reset(const DroneParams *p, int div_x, int div_y, float pitch,
                    uint64_t seed, int64_t env_base, const uint8_t *mask,
                    float *pos, float *vel, int32_t *t, int32_t *episode, int32_t *node_out,
                    int E, void *stream)
+{
+    return reset_impl(p, div_x, div_y, pitch, seed, env_base, mask, pos, vel, t, episode, node_out, nullptr, E, stream);
+}
+
+}   // extern "C"
+
+namespace {
+int reset_impl(const DroneParams *p, int div_x, int div_y, float pitch, uint64_t seed, int64_t env_base,
+               const uint8_t *mask, float *pos, float *vel, int32_t *t, int32_t *episode, int32_t *node_out,
+               double *acc, int E, void *stream)
 {
     if (!p) return fail(DRONESIM_EINVAL, "params is NULL");
     if (p->N < 1 || p->N > DRONESIM_MAX_AGENTS) return fail(DRONESIM_EUNSUPPORTED, "N must be in 1..1024");
@@ -1276,9 +1733,30 @@ int dronesim_reset(const DroneParams *p, int div_x, int div_y, float pitch,
     a.key0 = (uint32_t)seed;
     a.key1 = (uint32_t)(seed >> 32);
     a.env_base = env_base; a.pitch = pitch; a.mask = mask;
-    a.pos = pos; a.vel = vel; a.t = t; a.episode = episode; a.node_out = node_out;
+    a.pos = pos; a.vel = vel; a.t = t; a.episode = episode; a.node_out = node_out; a.acc = acc;
     const size_t lds = sizeof(int) * 2 * (size_t)g.epb * p->N;
     hipLaunchKernelGGL(reset_kernel, dim3(g.blocks), dim3(g.threads), lds, static_cast<hipStream_t>(stream), a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
+}
+}   // namespace
+
+extern "C" {
+
+int dronesim_reset_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, const uint8_t *mask,
+                      float *pos, float *vel, int32_t *t, int32_t *node_out, int E, void *stream)
+{
+    if (!ctl) return fail(DRONESIM_EINVAL, "dronesim_reset_ex: ctl is NULL");
+    return reset_impl(p, ctl->div_x, ctl->div_y, ctl->pitch, ctl->seed, ctl->env_base, mask, pos, vel, t, ctl->episode,
+                      node_out, reinterpret_cast<double *>(ctl->acc), E, stream);
+}
+
+int dronesim_episode_reduce(const DroneEpisodeAcc *acc, int E, double *out, void *stream)
+{
+    if (!acc || !out || E < 0) return fail(DRONESIM_EINVAL, "dronesim_episode_reduce: bad argument");
+    hipLaunchKernelGGL(episode_reduce_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const double *>(acc), E, out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

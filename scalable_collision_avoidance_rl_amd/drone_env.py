@@ -110,11 +110,16 @@ class drones:
     Signature and attributes follow the reference (drone_env.py:55); keyword-only
     additions: ``n_envs`` (E parallel, independent envs), ``device``, ``seed``,
     ``rank``/``world_size`` (shard the env axis across one-process-per-GPU ranks),
-    ``batched`` (force tensor API at E == 1)."""
+    ``batched`` (force tensor API at E == 1), ``track_episodes`` (keep the per-episode sums the
+    rollout loop logs, train_problem.py:98-100, in per-env device records updated by the step kernel
+    itself), ``auto_reset`` (envs whose ``done`` fires are reset and re-observed inside the same step
+    launch -- what train_problem.py:132 does after the ``while not finished`` loop; implies
+    ``track_episodes``)."""
 
     def __init__(self, n_agents: int, n_obstacles: int, grid: list, end_formation: str, k_closest=2,
                  deltas: np.ndarray = None, simplify_zstate=False, *, n_envs: int = 1, device=None,
-                 seed: int = None, rank: int = 0, world_size: int = 1, batched: bool = None) -> None:
+                 seed: int = None, rank: int = 0, world_size: int = 1, batched: bool = None,
+                 track_episodes: bool = None, auto_reset: bool = False) -> None:
         import torch
         from . import _native
 
@@ -135,7 +140,10 @@ class drones:
         self.simplify_zstate = bool(simplify_zstate)
         self.internal_t = 0
         self.collision_weight = 0.2                   # live attribute, read at every step (drone_env.py:72, 270)
-        self.drone_radius = np.ones(self.n_agents) * DRONE_RADIUS
+        self._drone_radius = np.ones(self.n_agents) * DRONE_RADIUS
+        self._alloc_done = False
+        self.auto_reset = bool(auto_reset)
+        self.track_episodes = self.auto_reset if track_episodes is None else bool(track_episodes) or self.auto_reset
         self.A = np.eye(dim)
         self.B = np.eye(dim) * dt
 
@@ -149,12 +157,12 @@ class drones:
             raise ValueError(str(end_formation) + " is Not a valid end formation identifier")
 
         self.obstacles = self.create_obstacles(n_obstacles)
-        self.end_points, self.d_safety = formation_O(N, grid, self.drone_radius)
+        self.end_points, self._d_safety = formation_O(N, grid, self.drone_radius)
         if not np.all(self.d_safety > 0):
             raise ValueError(f"safety distance d_hat = {self.d_safety.min():.2f} <= 0: the goal ring does not fit "
                              f"{N} agents on grid {grid} (need 0.9*G*sin(pi/N) > 0.2); the reference's reward is "
                              "degenerate there")
-        self.deltas = clip_deltas(deltas, self.d_safety)
+        self._deltas = clip_deltas(deltas, self.d_safety)
 
         # sharding of the env axis
         self.n_envs_global = int(n_envs)
@@ -164,6 +172,9 @@ class drones:
         if self.n_envs < 1:
             raise ValueError("this rank owns no environments")
         self.batched = (self.n_envs_global > 1) if batched is None else bool(batched)
+        if self.auto_reset and not self.batched:
+            raise ValueError("auto_reset needs the batched (tensor) API: the reference-typed E = 1 face mirrors "
+                             "the reference, whose caller resets explicitly (train_problem.py:132)")
         self.seed = int(np.random.SeedSequence().entropy & 0xFFFFFFFFFFFFFFFF) if seed is None else int(seed)
 
         self.global_state_space = N * (2 * dim + 1)
@@ -174,6 +185,21 @@ class drones:
 
         self._alloc()
         self.reset(renew_obstacles=False)
+
+    # ------------------------------------------------------------------ live constants
+    # The reference reads self.deltas / self.d_safety / self.drone_radius on every step (drone_env.py:242): assigning
+    # them here re-uploads the device copies and takes effect at the next launch.
+    def _set_const(self, name, value, tensor_name):
+        arr = np.array(value, np.float64).reshape(self.n_agents)
+        setattr(self, name, arr)
+        if self._alloc_done:
+            t = getattr(self, tensor_name)
+            t.copy_(self._torch.as_tensor(arr, dtype=self._torch.float32))
+            self._params_cache = None
+
+    deltas = property(lambda self: self._deltas, lambda self, v: self._set_const("_deltas", v, "_delta"))
+    d_safety = property(lambda self: self._d_safety, lambda self, v: self._set_const("_d_safety", v, "_d_hat"))
+    drone_radius = property(lambda self: self._drone_radius, lambda self, v: self._set_const("_drone_radius", v, "_radius"))
 
     # ------------------------------------------------------------------ buffers / params
     def _alloc(self):
@@ -199,6 +225,11 @@ class drones:
         self._act = torch.zeros(E, N, 2, **f32)
         self._params_cache = None
         self._step_args = None
+        # episode bookkeeping (include/dronesim.h: DroneEpisodeAcc, one 64-byte record per env) -- off unless asked for
+        self.episode_acc = torch.zeros(E, 8, dtype=torch.float64, device=dev) if self.track_episodes else None
+        self._episode_totals = torch.zeros(8, dtype=torch.float64, device=dev) if self.track_episodes else None
+        self._ctl_cache = None
+        self._alloc_done = True
         self.state = DroneState(self.pos, self.vel, self._radius) if self.batched else None
         # step() hands back the same live tensors every call
         self._result = StepResult(self.state, self.z, self.reward, self.n_coll, self.done, self.true_reward)
@@ -227,6 +258,23 @@ class drones:
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _ctl(self):
+        """DroneEpisodeCtl of this env (None when neither bookkeeping nor auto-reset is on)."""
+        if self._ctl_cache is None:
+            c = self._native.DroneEpisodeCtl()
+            c.acc = self.episode_acc.data_ptr() if self.episode_acc is not None else None
+            c.auto_reset = 1 if self.auto_reset else 0
+            c.div_x, c.div_y = lattice_divisions(self.grid)
+            c.pitch = float(LATTICE_PITCH)
+            c.seed, c.env_base = self.seed, self.env_lo
+            c.episode = self.episode.data_ptr()
+            self._ctl_cache = c
+        return self._ctl_cache
+
+    @property
+    def _use_ctl(self):
+        return self.track_episodes or self.auto_reset
+
     # ------------------------------------------------------------------ reference API
     def create_obstacles(self, n_obstacles):
         """Cosmetic obstacles (never read by dynamics or reward) -- drone_env.py:155-169."""
@@ -250,10 +298,15 @@ class drones:
         dx, dy = lattice_divisions(self.grid)
         p = self._params()
         with torch.cuda.device(self.device):
-            rc = self._lib.dronesim_reset(C.byref(p), dx, dy, float(LATTICE_PITCH), self.seed,
-                                          self.env_lo, None if m is None else m.data_ptr(),
-                                          self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
-                                          self.episode.data_ptr(), None, self.n_envs, self._stream())
+            if self._use_ctl:                        # also retires the episode records of the envs it resets
+                rc = self._lib.dronesim_reset_ex(C.byref(p), C.byref(self._ctl()), None if m is None else m.data_ptr(),
+                                                 self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
+                                                 None, self.n_envs, self._stream())
+            else:
+                rc = self._lib.dronesim_reset(C.byref(p), dx, dy, float(LATTICE_PITCH), self.seed,
+                                              self.env_lo, None if m is None else m.data_ptr(),
+                                              self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
+                                              self.episode.data_ptr(), None, self.n_envs, self._stream())
             self._native.check(rc, "dronesim_reset")
             self._observe(m)
         if m is None:
@@ -272,13 +325,19 @@ class drones:
                                         None if mask is None else mask.data_ptr(), self.n_envs, self._stream())
         self._native.check(rc, "dronesim_observe")
 
-    def step(self, actions):
+    def step(self, actions, copy=False):
         """One env.step() for every env (drone_env.py:214-258).
 
         Compat mode (E == 1): ``actions`` is any indexable of N array-likes ``[2]`` (list or deque);
         returns ``(state, z_states, r_vec, n_collisions, finished, true_r_vec)`` in the reference's
         types.  Batched mode: ``actions`` is a ``[E,N,2]`` float32 tensor on this env's device;
-        returns a `StepResult` of device tensors (no host sync)."""
+        returns a `StepResult` of device tensors (no host sync).  NOTE: those are the env's LIVE buffers, the
+        same objects on every call and overwritten by the next launch (the reference returns fresh arrays each
+        step); pass ``copy=True`` -- or clone what you keep -- when storing results across steps.
+
+        With ``auto_reset`` an env whose ``finished`` flag fires is re-sampled and re-observed inside this
+        launch: rewards / n_collisions / finished describe the finished episode's last transition, state and
+        z_states are the new episode's first ones."""
         torch = self._torch
         if self.batched:
             act = actions
@@ -299,39 +358,55 @@ class drones:
         # only the action pointer and the current stream vary per call
         args = self._step_args
         if args is None:
-            args = self._step_args = [C.byref(p)] + [C.c_void_p(t.data_ptr()) for t in (
-                self.pos, self.vel, self.t, self._act, self.reward, self.true_reward, self.z, self.nbr_idx,
-                self.n_coll, self.done)] + [self.n_envs, None]
+            args = self._step_args = [C.byref(p), C.byref(self._ctl()) if self._use_ctl else None] + [
+                C.c_void_p(t.data_ptr()) for t in (
+                    self.pos, self.vel, self.t, self._act, self.reward, self.true_reward, self.z, self.nbr_idx,
+                    self.n_coll, self.done)] + [self.n_envs, None]
         args[0] = C.byref(p)
-        args[4] = C.c_void_p(act.data_ptr())
+        args[5] = C.c_void_p(act.data_ptr())
         if torch.cuda.current_device() == self.device.index:
-            args[12] = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            rc = self._lib.dronesim_step(*args)
+            args[13] = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = self._lib.dronesim_step_ex(*args)
         else:
             with torch.cuda.device(self.device):
-                args[12] = self._stream()
-                rc = self._lib.dronesim_step(*args)
+                args[13] = self._stream()
+                rc = self._lib.dronesim_step_ex(*args)
         if rc:
             self._native.check(rc, "dronesim_step")
         if self.batched:
+            if copy:
+                return StepResult(DroneState(self.pos.clone(), self.vel.clone(), self._radius), self.z.clone(),
+                                  self.reward.clone(), self.n_coll.clone(), self.done.clone(), self.true_reward.clone())
             return self._result
         self._sync_host_views()
         self.internal_t += 1
         return (self.state, self.z_states, self._host_reward, self._host_n_coll, self._host_done,
                 self._host_true_reward)
 
-    def rollout(self, actions, with_pre=False):
+    def rollout_random(self, T, record_actions=False, with_pre=False):
+        """T fused steps whose actions are drawn inside the kernel (RandomAgent.forward, SAC_agents.py:9-22):
+        no action pool is read.  The stream is keyed by (seed, global env id, agent, t, episode), so results do
+        not depend on the sharding or on how T is split into calls.  ``record_actions`` adds ``actions [T,E,N,2]``."""
+        return self.rollout(None, with_pre=with_pre, _random=(int(T), bool(record_actions)))
+
+    def rollout(self, actions, with_pre=False, _random=None):
         """T fused steps in one launch with the actions known up front (RandomAgent-style rollouts,
         SAC_agents.py:9-22 + train_problem.py:82-107).  ``actions``: ``[T,E,N,2]`` float32 device tensor.
         Returns a dict of ``[T, ...]`` tensors with every per-step output of step(); ``with_pre=True`` adds
         ``z_pre`` / ``nbr_idx_pre``, the observation each action was based on (what the reference stores as
-        ``z_state`` / ``Ni`` in its experience tuples, utils.py:236-249)."""
+        ``z_state`` / ``Ni`` in its experience tuples, utils.py:236-249).  With ``auto_reset`` the rollout runs
+        across episode ends (see step())."""
         torch = self._torch
         E, N, K1, c = self.n_envs, self.n_agents, self.k_closest + 1, self.c
-        act = actions.to(device=self.device, dtype=torch.float32).contiguous()
-        T = act.shape[0]
-        if tuple(act.shape) != (T, E, N, 2):
-            raise ValueError(f"actions must be [T,{E},{N},2], got {tuple(act.shape)}")
+        random_actions = _random is not None
+        if random_actions:
+            T = _random[0]
+            act = torch.empty(T, E, N, 2, dtype=torch.float32, device=self.device) if _random[1] else None
+        else:
+            act = actions.to(device=self.device, dtype=torch.float32).contiguous()
+            T = act.shape[0]
+            if tuple(act.shape) != (T, E, N, 2):
+                raise ValueError(f"actions must be [T,{E},{N},2], got {tuple(act.shape)}")
         f32 = dict(dtype=torch.float32, device=self.device)
         out = dict(reward=torch.empty(T, E, N, **f32), true_reward=torch.empty(T, E, N, **f32),
                    z=torch.empty(T, E, N, K1 * c, **f32),
@@ -341,15 +416,26 @@ class drones:
         if not self.batched:
             self._push_host_state()
         p = self._params()
+        z0, nb0 = (self.z.clone(), self.nbr_idx.clone()) if with_pre else (None, None)
         with torch.cuda.device(self.device):
-            rc = self._lib.dronesim_rollout(C.byref(p), self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
-                                            act.data_ptr(), out["reward"].data_ptr(), out["true_reward"].data_ptr(),
-                                            out["z"].data_ptr(), out["nbr_idx"].data_ptr(), out["n_coll"].data_ptr(),
-                                            out["done"].data_ptr(), E, T, self._stream())
+            if random_actions:
+                rc = self._lib.dronesim_rollout_random(
+                    C.byref(p), C.byref(self._ctl()), self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
+                    None if act is None else act.data_ptr(), out["reward"].data_ptr(), out["true_reward"].data_ptr(),
+                    out["z"].data_ptr(), out["nbr_idx"].data_ptr(), out["n_coll"].data_ptr(),
+                    out["done"].data_ptr(), E, T, self._stream())
+            else:
+                rc = self._lib.dronesim_rollout_ex(
+                    C.byref(p), C.byref(self._ctl()) if self._use_ctl else None, self.pos.data_ptr(),
+                    self.vel.data_ptr(), self.t.data_ptr(), act.data_ptr(), out["reward"].data_ptr(),
+                    out["true_reward"].data_ptr(), out["z"].data_ptr(), out["nbr_idx"].data_ptr(),
+                    out["n_coll"].data_ptr(), out["done"].data_ptr(), E, T, self._stream())
         self._native.check(rc, "dronesim_rollout")
+        if random_actions and act is not None:
+            out["actions"] = act
         if with_pre and T > 0:
-            out["z_pre"] = torch.cat([self.z.unsqueeze(0), out["z"][:-1]], dim=0)
-            out["nbr_idx_pre"] = torch.cat([self.nbr_idx.unsqueeze(0), out["nbr_idx"][:-1]], dim=0)
+            out["z_pre"] = torch.cat([z0.unsqueeze(0), out["z"][:-1]], dim=0)
+            out["nbr_idx_pre"] = torch.cat([nb0.unsqueeze(0), out["nbr_idx"][:-1]], dim=0)
         if T > 0:
             self.z.copy_(out["z"][-1]); self.nbr_idx.copy_(out["nbr_idx"][-1])
             self.reward.copy_(out["reward"][-1]); self.true_reward.copy_(out["true_reward"][-1])
@@ -359,18 +445,24 @@ class drones:
             self._sync_host_views()
         return out
 
-    def control(self, kind: str, u_max: float = 1.0):
+    def control(self, kind: str, u_max: float = 1.0, state=None):
         """Batched classical controllers evaluated on the CURRENT state (drone_env.py:609-679):
         ``kind`` = "proportional" or "gradient".  Returns actions ``[E,N,2]`` (device tensor) in batched
-        mode, a list of N float64 row vectors in compat mode -- directly usable as ``step()`` input."""
+        mode, a list of N float64 row vectors in compat mode -- directly usable as ``step()`` input.
+        ``state`` (compat mode, ``[N,5]``): evaluate on that state instead, leaving the env untouched."""
         torch = self._torch
         code = {"proportional": self._native.CONTROL_PROPORTIONAL, "gradient": self._native.CONTROL_GRADIENT}[kind]
+        pos = self.pos
         if not self.batched:
-            self._push_host_state()
+            if state is None:
+                self._push_host_state()
+            else:                                    # a hypothetical state: temporary device copy, env.state untouched
+                pos = torch.as_tensor(np.asarray(state, np.float64)[None, :, 0:2].astype(np.float32),
+                                      device=self.device).contiguous()
         act = torch.empty_like(self._act)
         p = self._params()
         with torch.cuda.device(self.device):
-            rc = self._lib.dronesim_control(C.byref(p), code, self.pos.data_ptr(), act.data_ptr(), float(u_max),
+            rc = self._lib.dronesim_control(C.byref(p), code, pos.data_ptr(), act.data_ptr(), float(u_max),
                                             self.n_envs, self._stream())
         self._native.check(rc, "dronesim_control")
         if self.batched:
@@ -408,9 +500,54 @@ class drones:
         self._sync_host_views()
 
     def get_state(self):
-        """``dict(pos, vel, t, episode, seed)`` clones -- everything needed to resume the env."""
-        return dict(pos=self.pos.clone(), vel=self.vel.clone(), t=self.t.clone(),
-                    episode=self.episode.clone(), seed=self.seed)
+        """``dict(pos, vel, t, episode, seed[, episode_acc])`` clones -- everything needed to resume the env."""
+        st = dict(pos=self.pos.clone(), vel=self.vel.clone(), t=self.t.clone(),
+                  episode=self.episode.clone(), seed=self.seed)
+        if self.episode_acc is not None:
+            st["episode_acc"] = self.episode_acc.clone()
+        return st
+
+    def load_state(self, state):
+        """Restore a `get_state()` checkpoint: positions, velocities, step counters AND the random-stream
+        position (``seed`` + per-env ``episode`` counters), so the resumed env draws the same initial states
+        (and in-kernel actions) as the original would have; then refresh the observation."""
+        torch = self._torch
+        self.seed = int(state["seed"])
+        self._ctl_cache = None
+        self._step_args = None
+        self.episode.copy_(torch.as_tensor(state["episode"], dtype=torch.int32).reshape(self.n_envs))
+        if self.episode_acc is not None and "episode_acc" in state:
+            self.episode_acc.copy_(torch.as_tensor(state["episode_acc"], dtype=torch.float64).reshape(self.n_envs, 8))
+        self.set_state(state["pos"], state["vel"], state["t"])
+
+    # ------------------------------------------------------------------ episode bookkeeping (train_problem.py:98-121)
+    def _acc_i32(self):
+        return self.episode_acc.view(self._torch.int32)               # [E,16] int32 view of the records
+
+    def episode_stats(self):
+        """Per-env view of the device records (no host sync): the episode in progress -- ``ep_return`` /
+        ``ep_true_return`` (sum over steps of the MEAN over agents, as train_problem.py:98-99 accumulates),
+        ``ep_collisions``, ``ep_len`` -- and totals over the episodes each env has completed."""
+        if self.episode_acc is None:
+            raise RuntimeError("construct the env with track_episodes=True (or auto_reset=True)")
+        a, ai, N = self.episode_acc, self._acc_i32(), self.n_agents
+        al = a.view(self._torch.int64)
+        return dict(ep_return=a[:, 0] / N, ep_true_return=a[:, 1] / N, ep_collisions=ai[:, 4], ep_len=ai[:, 5],
+                    episodes=ai[:, 6], done_return=a[:, 4] / N, done_true_return=a[:, 5] / N,
+                    done_collisions=al[:, 6], done_len=al[:, 7])
+
+    def episode_totals(self):
+        """One launch (`dronesim_episode_reduce`, fixed summation order): float64 ``[8]`` device tensor of this
+        rank's sums (done_return, done_true_return, done_collisions, done_len, episodes, ep_return, ep_true_return,
+        ep_len) with the returns summed over agents (divide by N for the reference's per-step mean).  This vector is
+        what multi-GPU runs all-gather (`sharding.EpisodeStats.reduce_env`)."""
+        if self.episode_acc is None:
+            raise RuntimeError("construct the env with track_episodes=True (or auto_reset=True)")
+        with self._torch.cuda.device(self.device):
+            rc = self._lib.dronesim_episode_reduce(self.episode_acc.data_ptr(), self.n_envs,
+                                                   self._episode_totals.data_ptr(), self._stream())
+        self._native.check(rc, "dronesim_episode_reduce")
+        return self._episode_totals
 
     # ------------------------------------------------------------------ compat-mode host views
     def _sync_host_views(self):
@@ -493,14 +630,10 @@ class drones:
 
 def gradient_control(state, env, u_max=1):
     """Drop-in for the reference's module-level `gradient_control(state, env, u_max)` (drone_env.py:609-650).
-    `state` is accepted for signature compatibility; in compat mode a modified `state` is uploaded first."""
-    if not env.batched and state is not env.state:
-        env.state[:, :] = state
-    return env.control("gradient", u_max)
+    Pure like the reference's: a `state` other than the env's own is evaluated without touching the env."""
+    return env.control("gradient", u_max, state=None if (env.batched or state is env.state) else state)
 
 
 def proportional_control(state, env):
-    """Drop-in for the reference's `proportional_control(state, env)` (drone_env.py:652-679)."""
-    if not env.batched and state is not env.state:
-        env.state[:, :] = state
-    return env.control("proportional", 1.0)
+    """Drop-in for the reference's `proportional_control(state, env)` (drone_env.py:652-679); pure."""
+    return env.control("proportional", 1.0, state=None if (env.batched or state is env.state) else state)

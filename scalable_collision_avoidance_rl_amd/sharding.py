@@ -51,19 +51,57 @@ class EpisodeStats:
         return summarize(all_gather_stats(self.vec, group))
 
 
-def all_gather_stats(vec, group=None):
-    """[world, len(vec)] tensor holding every rank's statistic vector (identity when not distributed)."""
+EPISODE_FIELDS = ("done_return", "done_true_return", "done_collisions", "done_len", "episodes",
+                  "ep_return", "ep_true_return", "ep_len")
+
+
+def reduce_episode_records(env, group=None):
+    """The path's only exchange, on the per-env episode records the step kernel keeps (include/dronesim.h:
+    DroneEpisodeAcc): one launch sums this rank's records in a fixed order (`dronesim_episode_reduce`), ONE
+    all-gather of the resulting 8-double vector (RCCL over xGMI under backend "nccl"; 64 B per rank) makes
+    every rank's sums available everywhere, and the global figures the reference logs per episode
+    (train_problem.py:118-121, 136-140) follow locally."""
+    return summarize_episodes(all_gather_stats(env.episode_totals(), group), env.n_agents)
+
+
+def summarize_episodes(gathered, n_agents):
+    """Global per-episode means from the gathered [world, 8] episode totals (returns are summed over agents on
+    the device; the reference accumulates the mean over agents per step: divide by N)."""
+    tot = gathered.double().sum(0)
+    eps = max(float(tot[4]), 1.0)
+    return {"episodes": float(tot[4]),
+            "mean_episode_reward": float(tot[0]) / n_agents / eps,
+            "mean_episode_true_reward": float(tot[1]) / n_agents / eps,
+            "mean_episode_collisions": float(tot[2]) / eps,
+            "mean_episode_len": float(tot[3]) / eps,
+            "env_steps": float(tot[3]) + float(tot[7]),
+            "agent_steps": (float(tot[3]) + float(tot[7])) * n_agents,
+            "mean_reward": (float(tot[0]) + float(tot[5])) / n_agents / max(float(tot[3]) + float(tot[7]), 1.0),
+            "mean_true_reward": (float(tot[1]) + float(tot[6])) / n_agents / max(float(tot[3]) + float(tot[7]), 1.0),
+            "collisions_per_env_step": float(tot[2]) / max(float(tot[3]), 1.0),
+            "world_size": int(gathered.shape[0])}
+
+
+def all_gather_stats(vec, group=None, async_op=False):
+    """[world, len(vec)] tensor holding every rank's statistic vector (identity when not distributed).
+    ``async_op=True`` returns ``(out, work)`` without making the current stream wait for the collective (RCCL runs it
+    on its own stream behind the producer of `vec`): the rollout's next launches are not held up; call
+    ``work.wait()`` (or synchronise) before reading ``out``."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return vec.view(1, -1).clone()
+        out = vec.view(1, -1).clone()
+        return (out, None) if async_op else out
     world = dist.get_world_size(group)
     src = vec.view(1, -1).contiguous()
     if dist.get_backend(group) == "gloo" and src.is_cuda:      # gloo gathers host tensors (CPU tests, debugging)
         src = src.cpu()
     out = torch.empty(world, vec.numel(), dtype=vec.dtype, device=src.device)
+    if async_op and src.is_cuda:
+        return out, dist.all_gather_into_tensor(out, src.clone(), group=group, async_op=True)
     dist.all_gather_into_tensor(out, src, group=group)
-    return out.to(vec.device)
+    out = out.to(vec.device)
+    return (out, None) if async_op else out
 
 
 def summarize(gathered):

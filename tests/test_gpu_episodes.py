@@ -1,0 +1,313 @@
+"""GPU tests of the episode layer of the hot path (round 2): per-env episode records accumulated by the step
+kernel itself (train_problem.py:98-100, 118-121), in-kernel auto-reset (drone_env.py:98-102 via
+train_problem.py:132), in-kernel RandomAgent actions (SAC_agents.py:9-22), checkpoint / resume.
+
+Everything goes through the C ABI (dronesim_step_ex / dronesim_rollout_ex / dronesim_rollout_random /
+dronesim_reset_ex / dronesim_episode_reduce) via the `drones` host class."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from oracle.oracle import Oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch
+
+
+def make_env(N, G, E, k=2, c=2, deltas=None, **kw):
+    from scalable_collision_avoidance_rl_amd import drones
+    deltas = np.ones(N) if deltas is None else deltas
+    return drones(N, 0, [G, G], "O", k_closest=k, deltas=deltas, simplify_zstate=(c == 2),
+                  n_envs=E, batched=True, device="cuda:0", seed=kw.pop("seed", 11), **kw)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def records(env):
+    return {k: host(v).copy() for k, v in env.episode_stats().items()}
+
+
+# ------------------------------------------------------------------------------- per-step accumulation
+@pytest.mark.parametrize("N,G,E,T", [(64, 28.0, 512, 200), (5, 5.0, 1000, 200), (130, 130.0, 24, 60), (48, 24.0, 100, 80)])
+def test_episode_records_accumulate_every_step(torch, N, G, E, T):
+    """ep_return / ep_true_return / ep_collisions / ep_len after T steps equal the sums of the per-step outputs
+    (train_problem.py:98-100 adds np.mean(rewards), np.mean(true_rewards), n_collisions on EVERY step), and agree
+    with the float64 oracle stepped on the same states and actions (teacher-forced, envs that stay margin-safe)."""
+    env = make_env(N, G, E, track_episodes=True, seed=5)
+    orc = Oracle(N, [G, G], 2, np.ones(N), True, threads=8)
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    own = np.zeros((3, E))
+    ref = np.zeros((3, E))
+    safe_all = np.ones(E, bool)
+    for s in range(T):
+        act = torch.rand(E, N, 2, device="cuda:0", generator=g) * 2 - 1
+        pos0 = host(env.pos).astype(np.float64); vel0 = host(env.vel).astype(np.float64); t0 = host(env.t).copy()
+        res = env.step(act)
+        own[0] += host(res.rewards).astype(np.float64).mean(1)
+        own[1] += host(res.true_rewards).astype(np.float64).mean(1)
+        own[2] += host(res.n_collisions)
+        if s % 4 == 0 or N <= 5:                       # oracle on a subsample of steps keeps the test in seconds
+            r = orc.step(pos0, vel0, t0, host(act).astype(np.float64))
+            safe = orc.margins(pos0) > H.MARGIN       # pos0 was integrated in place: the post-step state
+            safe_all &= safe
+            ref[0] += np.where(safe, r["reward"].mean(1), 0); ref[1] += np.where(safe, r["true_reward"].mean(1), 0)
+            ref[2] += np.where(safe, r["n_coll"], 0)
+            own_s = host(res.rewards).astype(np.float64).mean(1)
+            H.assert_close(own_s[safe], r["reward"].mean(1)[safe], f"step {s} mean reward", rtol=1e-5, atol=1e-5)
+    torch.cuda.synchronize()
+    rec = records(env)
+    assert np.array_equal(rec["ep_len"], np.full(E, T)) and np.array_equal(rec["ep_collisions"], own[2].astype(np.int64))
+    # the kernel adds float32 per-env sums (one fixed-order wave reduction per step) into float64 records
+    np.testing.assert_allclose(rec["ep_return"], own[0], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(rec["ep_true_return"], own[1], rtol=2e-6, atol=1e-6)
+    assert np.all(rec["episodes"] == 0) and np.all(rec["done_len"] == 0)
+    assert safe_all.any()
+    # explicit reset retires the episode (train_problem.py:118-121 then :132)
+    env.reset(renew_obstacles=False)
+    torch.cuda.synchronize()
+    rec2 = records(env)
+    assert np.all(rec2["episodes"] == 1) and np.all(rec2["ep_len"] == 0) and np.all(rec2["ep_return"] == 0)
+    np.testing.assert_array_equal(rec2["done_return"], rec["ep_return"])
+    np.testing.assert_array_equal(rec2["done_collisions"], rec["ep_collisions"])
+    np.testing.assert_array_equal(rec2["done_len"], np.full(E, T))
+    # the reduction every rank feeds into the exchange: fixed order, equals the host sum
+    tot = host(env.episode_totals())
+    a = host(env.episode_acc)
+    np.testing.assert_allclose(tot[0], a[:, 4].sum(), rtol=1e-13)
+    np.testing.assert_allclose(tot[1], a[:, 5].sum(), rtol=1e-13)
+    assert tot[2] == rec2["done_collisions"].sum() and tot[3] == E * T and tot[4] == E and tot[7] == 0
+    tot2 = host(env.episode_totals()).copy()
+    assert np.array_equal(tot, tot2)
+
+
+def test_bookkeeping_does_not_change_the_step(torch):
+    """The *_ex kernels with records on produce bit-identical step outputs to the plain kernels."""
+    for N, G, E, c in [(64, 28.0, 300, 2), (5, 5.0, 77, 2), (9, 8.0, 50, 5), (200, 200.0, 6, 2), (64, 28.0, 33, 5)]:
+        a = make_env(N, G, E, c=c, seed=9)
+        b = make_env(N, G, E, c=c, seed=9, track_episodes=True)
+        g = torch.Generator(device="cuda:0").manual_seed(1)
+        for s in range(6):
+            act = torch.rand(E, N, 2, device="cuda:0", generator=g) * 2 - 1
+            ra, rb = a.step(act), b.step(act)
+            for name in ("pos", "vel", "t", "reward", "true_reward", "z", "nbr_idx", "n_coll", "done"):
+                assert torch.equal(getattr(a, name), getattr(b, name)), (N, c, s, name)
+
+
+# ------------------------------------------------------------------------------- in-kernel auto-reset
+AUTO_SHAPES = [(5, 5.0, 300, 2, 2), (64, 28.0, 128, 2, 2), (48, 24.0, 40, 3, 2), (130, 130.0, 10, 2, 2),
+               (9, 8.0, 60, 2, 5), (64, 28.0, 20, 2, 5), (300, 300.0, 3, 2, 2)]
+
+
+@pytest.mark.parametrize("N,G,E,k,c", AUTO_SHAPES, ids=lambda v: str(v))
+def test_auto_reset_equals_step_then_masked_reset(torch, N, G, E, k, c):
+    """auto_reset=True (reset + re-observation inside the step launch) is bit-identical to what the reference's
+    loop does: step, then reset the envs whose `finished` fired (train_problem.py:82, 132): same fresh states
+    (same Philox stream as dronesim_reset), same observation, same retired episode records."""
+    A = make_env(N, G, E, k=k, c=c, seed=21, auto_reset=True)
+    B = make_env(N, G, E, k=k, c=c, seed=21, track_episodes=True)
+    assert torch.equal(A.pos, B.pos)
+    # stagger the time limit over the envs so that resets hit different envs at different steps, and drive a third
+    # of the envs with the P-controller so that some finish by ARRIVAL (drone_env.py:251)
+    t0 = (torch.arange(E, device="cuda:0", dtype=torch.int32) * 7) % 23 + 180
+    A.t.copy_(t0); B.t.copy_(t0)
+    g = torch.Generator(device="cuda:0").manual_seed(4)
+    n_done = 0
+    for s in range(40):
+        act = torch.rand(E, N, 2, device="cuda:0", generator=g) * 2 - 1
+        if N <= 9:
+            ctrl = B.control("proportional")
+            act[::3] = ctrl[::3]
+        ra = A.step(act)
+        rb = B.step(act, copy=True)
+        done = rb.finished.bool()
+        n_done += int(done.sum())
+        if bool(done.any()):
+            B.reset(renew_obstacles=False, mask=done)
+        for name, x, y in (("reward", ra.rewards, rb.rewards), ("true_reward", ra.true_rewards, rb.true_rewards),
+                           ("n_coll", ra.n_collisions, rb.n_collisions), ("done", ra.finished, rb.finished)):
+            assert torch.equal(x, y), (s, name)
+        for name in ("pos", "vel", "t", "z", "nbr_idx", "episode"):
+            assert torch.equal(getattr(A, name), getattr(B, name)), (s, name)
+        assert torch.equal(A.episode_acc, B.episode_acc), s
+    assert n_done >= E                                   # every env ended at least one episode
+    rec = records(A)
+    assert rec["episodes"].min() >= 1 and np.array_equal(rec["done_len"] + rec["ep_len"], 40 + 0 * rec["ep_len"])
+    if N <= 9:
+        assert (rec["done_len"][::3] < 100).any()        # arrival-terminated episodes are short
+
+
+def test_auto_reset_first_state_matches_the_oracle_reset(torch):
+    """The fresh state an env gets from the in-kernel reset is the oracle's `reset` draw for that episode counter."""
+    N, G, E = 64, 28.0, 64
+    env = make_env(N, G, E, seed=4242, auto_reset=True)
+    orc = Oracle(N, [G, G], 2, np.ones(N), True, threads=4)
+    rpos, rvel, rt, rnode, repi = orc.reset(E, 4242)
+    np.testing.assert_allclose(host(env.pos), rpos, rtol=1e-6, atol=1e-6)
+    env.t.fill_(199)
+    env.step(torch.zeros(E, N, 2, device="cuda:0"))
+    torch.cuda.synchronize()
+    r2 = orc.reset(E, 4242, pos=rpos, vel=rvel, t=rt, episode=repi)
+    np.testing.assert_allclose(host(env.pos), r2[0], rtol=1e-6, atol=1e-6)
+    assert int(env.t.abs().max()) == 0 and int(env.vel.abs().max()) == 0 and host(env.episode).tolist() == [2] * E
+    ref = orc.observe(host(env.pos).astype(np.float64))
+    safe = orc.margins(host(env.pos).astype(np.float64)) > H.MARGIN
+    np.testing.assert_array_equal(host(env.nbr_idx)[safe], ref["nbr_idx"][safe])
+
+
+def test_auto_reset_under_graph_replay_and_rollout(torch):
+    """A captured step with auto_reset replays across episode ends (all counters live on the device); the fused
+    rollout with auto_reset equals the same steps launched one by one."""
+    N, G, E, T = 64, 28.0, 96, 30
+    A = make_env(N, G, E, seed=3, auto_reset=True)
+    B = make_env(N, G, E, seed=3, auto_reset=True)
+    A.t.fill_(185); B.t.fill_(185)
+    g = torch.Generator(device="cuda:0").manual_seed(8)
+    act = torch.rand(T, E, N, 2, device="cuda:0", generator=g) * 2 - 1
+    out = A.rollout(act)
+    # B: the same steps through a captured graph of ONE step, replayed T times
+    buf = torch.zeros(E, N, 2, device="cuda:0")
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        B.step(buf)
+    for s in range(T):
+        buf.copy_(act[s])
+        graph.replay()
+        torch.cuda.synchronize()
+        for name, ref in (("reward", B.reward), ("true_reward", B.true_reward), ("z", B.z), ("nbr_idx", B.nbr_idx),
+                          ("n_coll", B.n_coll), ("done", B.done)):
+            assert torch.equal(out[name][s], ref), (name, s)
+    assert torch.equal(A.pos, B.pos) and torch.equal(A.t, B.t) and torch.equal(A.episode, B.episode)
+    assert torch.equal(A.episode_acc, B.episode_acc)
+    assert int(out["done"].sum()) == E and int(A.t[0]) == T - 15 and host(A.episode).tolist() == [2] * E
+
+
+# ------------------------------------------------------------------------------- in-kernel random actions
+@pytest.mark.parametrize("N,G,E,c", [(64, 28.0, 200, 2), (5, 5.0, 333, 2), (130, 130.0, 8, 2), (9, 8.0, 40, 5), (48, 24.0, 50, 2)])
+def test_rollout_random_stream_and_equivalence(torch, N, G, E, c):
+    """dronesim_rollout_random: the actions are bit-exactly the oracle's restatement of the documented Philox
+    stream (RandomAgent.forward, SAC_agents.py:9-22), the rollout equals dronesim_rollout fed with those actions,
+    splitting T over two calls changes nothing, and a shard sees exactly its slice."""
+    T = 21
+    A = make_env(N, G, E, c=c, seed=77)
+    B = make_env(N, G, E, c=c, seed=77)
+    A.t.fill_(3); B.t.fill_(3)
+    out = A.rollout_random(T, record_actions=True)
+    torch.cuda.synchronize()
+    acts = host(out["actions"])
+    epi = host(B.episode)
+    for s in range(T):
+        want = O.rand_actions(N, np.full(E, 3 + s, np.int32), epi, 77).astype(np.float32)
+        assert np.array_equal(acts[s], want), s
+    assert acts.min() >= -1.0 and acts.max() < 1.0
+    ref = B.rollout(out["actions"])
+    for name in ("reward", "true_reward", "z", "nbr_idx", "n_coll", "done"):
+        assert torch.equal(out[name], ref[name]), name
+    assert torch.equal(A.pos, B.pos) and torch.equal(A.vel, B.vel) and torch.equal(A.t, B.t)
+    # two calls == one call; no action record needed
+    Cc = make_env(N, G, E, c=c, seed=77); Cc.t.fill_(3)
+    o1 = Cc.rollout_random(8); o2 = Cc.rollout_random(T - 8)
+    assert torch.equal(torch.cat([o1["reward"], o2["reward"]]), out["reward"]) and torch.equal(Cc.pos, A.pos)
+    assert "actions" not in o1
+    # shard invariance (streams keyed by the global env id)
+    for r in range(2):
+        part = make_env(N, G, E, c=c, seed=77, rank=r, world_size=2); part.t.fill_(3)
+        po = part.rollout_random(T)
+        assert torch.equal(po["reward"], out["reward"][:, part.env_lo:part.env_hi])
+        assert torch.equal(part.pos, A.pos[part.env_lo:part.env_hi])
+
+
+def test_rollout_random_statistics_and_auto_reset(torch):
+    """U(-1,1) moments of the in-kernel actions; a random rollout with auto_reset runs through episode ends and keeps
+    the episode records (200-step episodes, one retired per env per 200 steps)."""
+    N, G, E, T = 64, 28.0, 256, 450
+    env = make_env(N, G, E, seed=5, auto_reset=True)
+    out = env.rollout_random(T, record_actions=True)
+    torch.cuda.synchronize()
+    a = host(out["actions"]).astype(np.float64)
+    n = a.size
+    assert abs(a.mean()) < 4 / np.sqrt(3 * n) and abs(a.var() - 1 / 3) < 1e-3
+    assert abs(np.corrcoef(a[:-1].ravel(), a[1:].ravel())[0, 1]) < 5e-3          # consecutive steps
+    assert abs(np.corrcoef(a[..., 0].ravel(), a[..., 1].ravel())[0, 1]) < 5e-3    # the two components
+    rec = records(env)
+    assert np.all(rec["episodes"] == 2) and np.all(rec["done_len"] == 400) and np.all(rec["ep_len"] == 50)
+    done = host(out["done"])
+    assert done[199].all() and done[399].all() and done.sum() == 2 * E
+    # actions of step 200 (first step of episode 2) use the incremented episode counter
+    want = O.rand_actions(N, np.zeros(E, np.int32), np.full(E, 2, np.int32), 5).astype(np.float32)
+    assert np.array_equal(host(out["actions"][200]), want)
+    own = host(out["reward"]).astype(np.float64).mean(2)          # [T, E]
+    np.testing.assert_allclose(rec["done_return"], own[:400].sum(0), rtol=2e-6)
+    np.testing.assert_allclose(rec["ep_return"], own[400:].sum(0), rtol=2e-6)
+
+
+# ------------------------------------------------------------------------------- checkpoint / live constants
+def test_checkpoint_resumes_the_same_streams(torch):
+    """get_state() / load_state(): a resumed env replays the SAME reset streams and in-kernel actions."""
+    N, G, E = 5, 5.0, 64
+    a = make_env(N, G, E, seed=31, auto_reset=True)
+    a.rollout_random(150)
+    ck = a.get_state()
+    cont = a.rollout_random(120)                       # crosses the 200-step limit: in-kernel resets
+    b = make_env(N, G, E, seed=999, auto_reset=True)  # a different env object, different seed
+    b.load_state(ck)
+    cont_b = b.rollout_random(120)
+    for name in ("reward", "z", "nbr_idx", "done"):
+        assert torch.equal(cont[name], cont_b[name]), name
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.episode, b.episode) and torch.equal(a.episode_acc, b.episode_acc)
+    assert int(cont["done"].sum()) == E
+
+
+def test_live_constants_are_reuploaded(torch):
+    """deltas / d_safety / drone_radius are read on every step by the reference (drone_env.py:242): assigning them
+    on the env re-uploads the device copies."""
+    N, G, E = 5, 5.0, 128
+    env = make_env(N, G, E, seed=2)
+    rng = np.random.default_rng(0)
+    pos = (2.5 + (rng.random((E, N, 2)) - 0.5) * 2.5).astype(np.float32)
+    zero = torch.zeros(E, N, 2, device="cuda:0")
+    env.set_state(pos); env.step(zero); r1 = env.reward.clone(); nb1 = env.nbr_idx.clone()
+    env.deltas = np.ones(N) * 0.3
+    env.set_state(pos); env.step(zero)
+    orc = Oracle(N, [G, G], 2, np.ones(N) * 0.3, True)
+    ref = orc.observe(pos.astype(np.float64))
+    safe = orc.margins(pos.astype(np.float64)) > H.MARGIN
+    np.testing.assert_array_equal(host(env.nbr_idx)[safe], ref["nbr_idx"][safe])
+    H.assert_close(host(env.reward)[safe], ref["reward"][safe], "reward after deltas change")
+    assert not torch.equal(nb1, env.nbr_idx) and not torch.equal(r1, env.reward)
+
+
+def test_step_copy_returns_fresh_tensors(torch):
+    env = make_env(5, 5.0, 16, seed=1)
+    act = torch.rand(16, 5, 2, device="cuda:0")
+    r1 = env.step(act, copy=True)
+    keep = r1.rewards.clone()
+    r2 = env.step(act, copy=True)
+    assert r1.rewards.data_ptr() != r2.rewards.data_ptr() and torch.equal(r1.rewards, keep)
+    assert not torch.equal(r1.rewards, r2.rewards)
+    live = env.step(act)
+    assert live.rewards.data_ptr() == env.reward.data_ptr()
+
+
+def test_ex_entry_points_reject_bad_arguments(torch):
+    import ctypes as C
+    env = make_env(5, 5.0, 4, seed=1, track_episodes=True)
+    lib, nat = env._lib, env._native
+    p = env._params()
+    ctl = nat.DroneEpisodeCtl(); ctl.auto_reset = 1                      # no episode pointer
+    args = [env.pos, env.vel, env.t, env._act, env.reward, env.true_reward, env.z, env.nbr_idx, env.n_coll, env.done]
+    rc = lib.dronesim_step_ex(C.byref(p), C.byref(ctl), *[C.c_void_p(t.data_ptr()) for t in args], 4, None)
+    assert rc == nat.EINVAL and b"episode" in lib.dronesim_last_error()
+    rc = lib.dronesim_rollout_random(C.byref(p), None, *[C.c_void_p(t.data_ptr()) for t in args], 4, 3, None)
+    assert rc == nat.EINVAL
+    assert lib.dronesim_episode_reduce(None, 4, None, None) == nat.EINVAL
+    assert lib.dronesim_reset_ex(C.byref(p), None, None, None, None, None, None, 4, None) == nat.EINVAL

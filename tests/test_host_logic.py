@@ -64,7 +64,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == sorted(_native.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dronesim_version() == 100
+    assert lib.dronesim_version() == 200
     assert lib.dronesim_error_string(0) == b"ok"
     assert b"invalid" in lib.dronesim_error_string(_native.EINVAL)
 
@@ -75,6 +75,36 @@ def test_params_struct_layout_matches_header():
     names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|float)\s*\*?\s*(\w+);", body, re.M)
     assert names == [f[0] for f in _native.DroneParams._fields_]
     assert C.sizeof(_native.DroneParams) == 4 * 4 + 11 * 4 + 4 + 4 * 8     # 4-byte pad before the pointers
+
+
+def test_episode_structs_match_header():
+    """ctypes mirrors of DroneEpisodeAcc / DroneEpisodeCtl (field order, sizes) against include/dronesim.h."""
+    header = open(_native.HEADER_PATH).read()
+    for cls, name in ((_native.DroneEpisodeAcc, "DroneEpisodeAcc"), (_native.DroneEpisodeCtl, "DroneEpisodeCtl")):
+        body = header[header.index("typedef struct %s {" % name):header.index("} %s;" % name)]
+        names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|int64_t|uint64_t|float|double|DroneEpisodeAcc)\s*\*?\s*(\w+);", body, re.M)
+        assert names == [f[0] for f in cls._fields_], name
+    assert C.sizeof(_native.DroneEpisodeAcc) == 64 and C.sizeof(_native.DroneEpisodeCtl) == 48
+    assert _native.DroneEpisodeAcc.done_return.offset == 32 and _native.DroneEpisodeAcc.ep_len.offset == 20
+    assert _native.DroneEpisodeCtl.seed.offset == 24 and _native.DroneEpisodeCtl.episode.offset == 40
+
+
+def test_philox_restatement_matches_the_published_known_answers():
+    """The oracle's Philox4x32-10 (reset stream, in-kernel RandomAgent actions) against the Random123 known-answer
+    vectors (Salmon et al., SC'11, kat_vectors: philox4x32 10 rounds)."""
+    from oracle import oracle as O
+    assert O.philox([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert O.philox([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert O.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+    assert O.philox_word0(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0) == 0xd16cfe09
+    # RandomAgent stream: values on the 2^24-point grid of [-1, 1), exact in float32, pairs (t even / odd) share a block
+    a0 = O.rand_actions(4, np.array([6, 7], np.int32), np.array([2, 2], np.int32), 99, env_base=5)
+    assert a0.min() >= -1 and a0.max() < 1 and np.array_equal(a0, a0.astype(np.float32).astype(np.float64))
+    w = O.philox([1, 5, 3, 2], [99 ^ 0x52414E44, 0])
+    assert a0[0, 1, 0] == -1 + (w[0] >> 8) * 2.0 ** -23 and a0[0, 1, 1] == -1 + (w[1] >> 8) * 2.0 ** -23
+    w1 = O.philox([1, 6, 3, 2], [99 ^ 0x52414E44, 0])
+    assert a0[1, 1, 0] == -1 + (w1[2] >> 8) * 2.0 ** -23 and a0[1, 1, 1] == -1 + (w1[3] >> 8) * 2.0 ** -23
 
 
 def test_argument_errors_are_reported_without_a_gpu():

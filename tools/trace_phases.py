@@ -15,7 +15,7 @@ from tools.kbench import PRESETS
 
 spec = sys.argv[1] if len(sys.argv) > 1 else "c3"
 N, E, G, delta = PRESETS[spec]
-env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1)
+env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1, track_episodes=bool(os.environ.get("TRACK")), auto_reset=bool(os.environ.get("AUTO")))
 lib = _native.lib()
 waves = E * max(1, (N + 63) // 64) if N > 64 else (E + (64 // N) - 1) // (64 // N)
 trace = torch.zeros(waves, 8, dtype=torch.int64, device="cuda")
