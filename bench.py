@@ -226,7 +226,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter(); graph.replay(); torch.cuda.synchronize()
         one = max(time.perf_counter() - t0, 1e-6)
-        repeats = max(1, int(np.ceil(args.min_seconds / one)))
+        repeats = max(1, int(np.ceil(1.2 * args.min_seconds / one)))
     else:
         repeats = 1
     log_every = max(1, T_ep // K) if K < T_ep else 1     # replays between two exchanges (~ once per episode)

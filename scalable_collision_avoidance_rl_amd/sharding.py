@@ -61,7 +61,13 @@ def reduce_episode_records(env, group=None):
     all-gather of the resulting 8-double vector (RCCL over xGMI under backend "nccl"; 64 B per rank) makes
     every rank's sums available everywhere, and the global figures the reference logs per episode
     (train_problem.py:118-121, 136-140) follow locally."""
-    return summarize_episodes(all_gather_stats(env.episode_totals(), group), env.n_agents)
+    return reduce_episode_totals(env.episode_totals(), env.n_agents, group)
+
+
+def reduce_episode_totals(totals, n_agents, group=None):
+    """`reduce_episode_records` on an already reduced per-rank 8-vector (`drones.episode_totals()`; a host tensor in
+    the gloo tests of the exchange)."""
+    return summarize_episodes(all_gather_stats(totals, group), n_agents)
 
 
 def summarize_episodes(gathered, n_agents):
@@ -82,14 +88,15 @@ def summarize_episodes(gathered, n_agents):
             "world_size": int(gathered.shape[0])}
 
 
-def all_gather_stats(vec, group=None, async_op=False):
+def all_gather_stats(vec, group=None, async_op=False, force_collective=False):
     """[world, len(vec)] tensor holding every rank's statistic vector (identity when not distributed).
     ``async_op=True`` returns ``(out, work)`` without making the current stream wait for the collective (RCCL runs it
     on its own stream behind the producer of `vec`): the rollout's next launches are not held up; call
-    ``work.wait()`` (or synchronise) before reading ``out``."""
+    ``work.wait()`` (or synchronise) before reading ``out``.  ``force_collective`` runs the collective even in a
+    world of one (smoke test of the RCCL path on a single GPU)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force_collective):
         out = vec.view(1, -1).clone()
         return (out, None) if async_op else out
     world = dist.get_world_size(group)

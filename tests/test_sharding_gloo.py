@@ -15,7 +15,9 @@ import torch.multiprocessing as mp
 
 from oracle.oracle import Oracle
 from scalable_collision_avoidance_rl_amd import shard_range
-from scalable_collision_avoidance_rl_amd.sharding import EpisodeStats, all_gather_stats, summarize
+from scalable_collision_avoidance_rl_amd.sharding import (EpisodeStats, all_gather_stats, summarize, reduce_episode_totals,
+                                                         summarize_episodes)
+from oracle import oracle as O
 
 N, E, G, T = 5, 12, 5.0, 6
 
@@ -32,6 +34,21 @@ def _rollout(lo, hi):
     return node, outs
 
 
+def _episode_totals(lo, hi, T2=7):
+    """What `drones.episode_totals()` holds for global envs [lo, hi) after T2 steps with the in-kernel RandomAgent
+    stream (keyed by the GLOBAL env id, so a shard draws exactly its slice) and one reset: restated with the oracle."""
+    orc = Oracle(N, [G, G], 2, np.ones(N), True)
+    n = hi - lo
+    pos, vel, t, _, epi = orc.reset(n, seed=31, env_base=lo)
+    ret = np.zeros(n); tret = np.zeros(n); coll = np.zeros(n); length = np.zeros(n)
+    for s in range(T2):
+        act = O.rand_actions(N, t, epi, 31, env_base=lo)
+        o = orc.step(pos, vel, t, act)
+        ret += o["reward"].sum(1); tret += o["true_reward"].sum(1); coll += o["n_coll"]; length += 1
+    # records after retiring the episode: (done_return, done_true_return, done_collisions, done_len, episodes, 0, 0, 0)
+    return torch.tensor([ret.sum(), tret.sum(), coll.sum(), length.sum(), float(n), 0.0, 0.0, 0.0], dtype=torch.float64)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -44,7 +61,8 @@ def _worker(rank, world, port, q):
                         torch.from_numpy(o["n_coll"]))
         g = all_gather_stats(st.vec)
         assert g.shape == (world, 5)
-        q.put((rank, lo, hi, node, st.reduce()))
+        epi_summary = reduce_episode_totals(_episode_totals(lo, hi), N)     # the record-based exchange (round 2)
+        q.put((rank, lo, hi, node, st.reduce(), epi_summary))
     finally:
         dist.destroy_process_group()
 
@@ -73,6 +91,13 @@ def test_sharded_statistic_equals_unsharded():
         assert got["world_size"] == 2 and got["agent_steps"] == want["agent_steps"] == N * E * T
         for k in ("mean_reward", "mean_true_reward", "collisions_per_env_step"):
             assert got[k] == pytest.approx(want[k], rel=1e-12)
+    # record-based exchange: the gathered per-rank totals reproduce the unsharded figures
+    want_e = summarize_episodes(_episode_totals(0, E).view(1, -1), N)
+    for r in res:
+        got = r[5]
+        assert got["world_size"] == 2 and got["episodes"] == E and got["mean_episode_len"] == 7
+        for k in ("mean_episode_reward", "mean_episode_true_reward", "mean_episode_collisions", "mean_reward"):
+            assert got[k] == pytest.approx(want_e[k], rel=1e-12), k
 
 
 def test_single_process_reduce_is_identity():
