@@ -274,6 +274,35 @@ int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, float *out,
                               uint64_t seed, uint64_t counter, int64_t env_base,
                               const int32_t *t, const int32_t *episode, int E, void *stream);
 
+/* ---- float64 VERIFICATION variant (test infrastructure of the float32 product kernels; csrc/verify_f64.hip) -------
+ * The reference computes in float64 (drone_env.py:189).  dronesim_step_f64 / dronesim_observe_f64 run the same
+ * per-pair arithmetic (one scalar-type template, instantiated for double) and epilogue semantics as dronesim_step /
+ * dronesim_observe on float64 buffers -- one workgroup per env, every ordered pair visited, no far filter: slow and
+ * simple.  They exist so that the parity tests can (1) meet the reference's golden vectors with no float32-state
+ * allowance, (2) follow a free-running 200-step episode of the float64 oracle, (3) judge the float32 kernels against
+ * a float64 evaluation of the same state on the device.  Layouts as in dronesim_step with double instead of float.  */
+typedef struct DroneParamsF64 {
+    int32_t N;
+    int32_t k;
+    int32_t c;
+    int32_t max_steps;
+    double dt;
+    double q;
+    double b;
+    double done_radius;
+    double ghost_factor;
+    const double *xF;       /* [N][2] */
+    const double *d_hat;    /* [N]    */
+    const double *delta;    /* [N]    */
+    const double *radius;   /* [N]    */
+} DroneParamsF64;
+int dronesim_step_f64(const DroneParamsF64 *p, double *pos, double *vel, int32_t *t, const double *act,
+                      double *reward, double *true_reward, double *z, int32_t *nbr_idx,
+                      int32_t *n_coll, uint8_t *done, int E, void *stream);
+int dronesim_observe_f64(const DroneParamsF64 *p, const double *pos, const double *vel,
+                         double *reward, double *true_reward, double *z, int32_t *nbr_idx,
+                         int32_t *n_coll, int E, void *stream);
+
 const char *dronesim_last_error(void);
 const char *dronesim_error_string(int code);
 int dronesim_version(void);

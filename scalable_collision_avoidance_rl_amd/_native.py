@@ -25,6 +25,7 @@ STATS_SCRATCH_DOUBLES = 193          # DRONESIM_STATS_SCRATCH_DOUBLES (include/d
 EPISODE_REDUCE_DOUBLES = 8           # DRONESIM_EPISODE_REDUCE_DOUBLES
 SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_episode_stats", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
            "dronesim_step_ex", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
+           "dronesim_step_f64", "dronesim_observe_f64",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -51,6 +52,14 @@ class DroneEpisodeCtl(C.Structure):
     """Mirror of `struct DroneEpisodeCtl` (include/dronesim.h)."""
     _fields_ = [("acc", C.c_void_p), ("auto_reset", C.c_int32), ("div_x", C.c_int32), ("div_y", C.c_int32),
                 ("pitch", C.c_float), ("seed", C.c_uint64), ("env_base", C.c_int64), ("episode", C.c_void_p)]
+
+
+class DroneParamsF64(C.Structure):
+    """Mirror of `struct DroneParamsF64` (include/dronesim.h): the float64 verification variant."""
+    _fields_ = [("N", C.c_int32), ("k", C.c_int32), ("c", C.c_int32), ("max_steps", C.c_int32),
+                ("dt", C.c_double), ("q", C.c_double), ("b", C.c_double), ("done_radius", C.c_double),
+                ("ghost_factor", C.c_double),
+                ("xF", C.c_void_p), ("d_hat", C.c_void_p), ("delta", C.c_void_p), ("radius", C.c_void_p)]
 
 
 class DroneMlp(C.Structure):
@@ -112,6 +121,10 @@ def lib():
     L.dronesim_rollout_random.argtypes = [P, PC] + [vp] * 10 + [i32, i32, vp]
     L.dronesim_reset_ex.argtypes = [P, PC] + [vp] * 5 + [i32, vp]
     L.dronesim_episode_reduce.argtypes = [vp, i32, vp, vp]
+    P64 = C.POINTER(DroneParamsF64)
+    L.dronesim_step_f64.argtypes = [P64] + [vp] * 10 + [i32, vp]
+    L.dronesim_observe_f64.argtypes = [P64] + [vp] * 7 + [i32, vp]
+    L.dronesim_step_f64.restype = L.dronesim_observe_f64.restype = C.c_int
     for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset", "dronesim_step_ex",
                  "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
                  "dronesim_episode_stats", "dronesim_version"):

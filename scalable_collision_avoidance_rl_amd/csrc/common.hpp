@@ -20,3 +20,41 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+
+// ---- the arithmetic of ONE ordered pair (i, j) of distance_data (drone_env.py:309-332), templated on the scalar type:
+// the float32 instantiation is the hot kernels' pass 2, the float64 one is the verification kernel (drone_kernel_f64,
+// test-only) that is compared with the float64 oracle without any float32-state allowance.
+template <typename Real> struct RealOps;
+template <> struct RealOps<float> {
+    static __device__ __forceinline__ float sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float log2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32 = log2
+    static __device__ __forceinline__ float rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+    static __device__ __forceinline__ float fma(float a, float b, float c) { return fmaf(a, b, c); }
+    static __device__ __forceinline__ float min(float a, float b) { return fminf(a, b); }
+};
+template <> struct RealOps<double> {
+    static __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+    static __device__ __forceinline__ double log2(double x) { return ::log2(x); }
+    static __device__ __forceinline__ double rsqrt(double x) { return 1.0 / ::sqrt(x); }
+    static __device__ __forceinline__ double fma(double a, double b, double c) { return ::fma(a, b, c); }
+    static __device__ __forceinline__ double min(double a, double b) { return ::fmin(a, b); }
+};
+
+template <typename Real> struct PairTerms { Real d, lg; bool coll, inm; };
+
+// d2 = |x_i - x_j|^2 of the pair; l_i, l_j radii; dhat_i and log2(dhat_i) of the ROW; Delta_j of the COLUMN (Q1)
+template <typename Real>
+__device__ __forceinline__ PairTerms<Real> pair_terms(Real d2, Real li, Real lj, Real dhat, Real log2_dhat, Real delta_j)
+{
+    PairTerms<Real> r;
+    const Real dist = RealOps<Real>::sqrt(d2);
+    Real d = RealOps<Real>::min(dist - li - lj, dhat);                        // :318
+    d = (d == Real(0)) ? Real(-1e-6) : d;                                     // :319-320
+    r.coll = d < Real(0);                                                     // :327 (dhat > 0)
+    // log(dhat/d) = ln2 * (log2 dhat - log2 d); collisions contribute 9990 (:330-332)
+    r.lg = r.coll ? Real(9.99e3) : Real(0.693147180559945309417232121458) * (log2_dhat - RealOps<Real>::log2(d));
+    r.inm = d <= delta_j;                                                     // :328 (Delta_j!)
+    r.d = d;
+    return r;
+}
+

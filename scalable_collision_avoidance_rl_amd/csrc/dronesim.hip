@@ -527,18 +527,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             const float dx = xi - pj.x, dy = yi - pj.y;
             const float d2 = fmaf(dy, dy, dx * dx);
             if (CACHED && !(d2 < thr)) return;                                // listed but currently far
-            const float dist = __builtin_amdgcn_sqrtf(d2);
-            float d = fminf(dist - li - cj.y, dhat);                          // :318
-            d = (d == 0.0f) ? -1e-6f : d;                                     // :319-320
-            const bool coll = d < 0.0f;                                       // :327 (dhat > 0)
-            // log(dhat/d) = ln2 * (log2 dhat - log2 d); collisions contribute 9990 (:330-332)
-            const float lg = coll ? 9.99e3f : kLn2 * (log2_dhat - __builtin_amdgcn_logf(d));
-            const bool inm = d <= cj.x;                                       // :328 (Delta_j!)
-            s_all += lg;                                                      // :283
-            s_msk += inm ? lg : 0.0f;                                         // :282
-            ncoll += coll ? 1 : 0;                                            // :284
-            in_range += inm ? 1 : 0;
-            nbr_insert<K>(list, nbr_key(d, j));                               // :338
+            const PairTerms<float> pt = pair_terms<float>(d2, li, cj.y, dhat, log2_dhat, cj.x);
+            s_all += pt.lg;                                                   // :283
+            s_msk += pt.inm ? pt.lg : 0.0f;                                   // :282
+            ncoll += pt.coll ? 1 : 0;                                         // :284
+            in_range += pt.inm ? 1 : 0;
+            nbr_insert<K>(list, nbr_key(pt.d, j));                            // :338
         };
 
         // @phase filter_generic2

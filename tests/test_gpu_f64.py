@@ -1,0 +1,121 @@
+"""The float64 verification variant of the env step (csrc/verify_f64.hip, test infrastructure for the float32 kernels).
+
+The reference is float64 (drone_env.py:189).  With the same per-pair template instantiated for double on the GPU:
+  * the reference's golden vectors are met to 1e-9 -- no `1e-5 + ulp32(G)` widening, also at N = 256 / G = 256;
+  * a free-running 200-step C3 episode follows the float64 oracle (the float32 kernels can only be teacher-forced);
+  * the float32 product kernels are judged against a float64 evaluation of the same float32 states ON the device."""
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TIGHT = dict(rtol=1e-9, atol=1e-9)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def f64_env(N, G, k, c, deltas, E, **kw):
+    from scalable_collision_avoidance_rl_amd.verify import F64Env
+    return F64Env(N, [G, G], k, deltas, c == 2, n_envs=E, device="cuda:0", **kw)
+
+
+@pytest.mark.parametrize("path", H.single_step_files(), ids=lambda p: p.split("single_step_")[1][:-4])
+def test_golden_single_steps_in_float64(torch, path):
+    """Teacher-forced env.step() cases produced by the reference (drone_env.py:214-401), flat 1e-9 on every output."""
+    fx = np.load(path)
+    E, c, N = fx["pos0"].shape[0], int(fx["c"]), int(fx["N"])
+    env = f64_env(N, float(fx["G"]), int(fx["k"]), c, fx["deltas"], E, collision_weight=float(fx["collision_weight"]))
+    np.testing.assert_array_equal(env.d_safety, H.oracle_for(fx).d_hat)
+    env.set_state(fx["pos0"], fx["vel0"], fx["t0"])
+    env.step(torch.tensor(fx["act"], dtype=torch.float64, device="cuda:0"))
+    torch.cuda.synchronize()
+    H.assert_close(host(env.pos), fx["pos1"], "pos", rtol=0, atol=1e-14)
+    np.testing.assert_array_equal(host(env.vel), fx["vel1"])
+    np.testing.assert_array_equal(host(env.t), fx["t0"] + 1)
+    np.testing.assert_array_equal(host(env.done).astype(bool), fx["done"])
+    np.testing.assert_array_equal(host(env.n_coll), fx["n_coll"])
+    np.testing.assert_array_equal(host(env.nbr_idx), fx["nbr_idx"])
+    H.assert_close(host(env.reward), fx["reward"], "reward", **TIGHT)
+    H.assert_close(host(env.true_reward), fx["true_reward"], "true_reward", **TIGHT)
+    K1 = int(fx["k"]) + 1
+    z = host(env.z).reshape(E, N, K1, c)
+    m = H.z_compare_mask(fx["nbr_idx"], fx["row_tie_free"], c)
+    H.assert_close(np.where(m, z, 0), np.where(m, fx["z"], 0), "z", **TIGHT)      # flat: no ulp32(G) term
+
+
+def test_free_running_c3_episode_follows_the_oracle(torch):
+    """200 free-running steps at the C3 shape (N = 64, G = 28), random actions: float64 GPU vs float64 oracle, every
+    step, every env -- rewards, collisions, neighbour lists, done -- no teacher forcing, no margin filter beyond exact
+    ties (the two sides differ by float64 round-off only)."""
+    N, G, E, T = 64, 28.0, 192, 200
+    orc = Oracle(N, [G, G], 2, np.ones(N), True, threads=8)
+    env = f64_env(N, G, 2, 2, np.ones(N), E)
+    pos, vel, t, _, _ = orc.reset(E, 99)
+    env.set_state(pos, vel, t)
+    rng = np.random.default_rng(0)
+    ret = np.zeros(E); ret_ref = np.zeros(E)
+    checked = 0
+    for s in range(T):
+        act = rng.uniform(-1, 1, (E, N, 2))
+        ref = orc.step(pos, vel, t, act)
+        env.step(torch.tensor(act, device="cuda:0"))
+        ok = orc.margins(pos) > 1e-9                                   # only exact-tie envs are skipped
+        checked += int(ok.sum())
+        H.assert_close(host(env.pos), pos, f"pos@{s}", rtol=0, atol=1e-11)
+        np.testing.assert_array_equal(host(env.n_coll)[ok], ref["n_coll"][ok])
+        np.testing.assert_array_equal(host(env.nbr_idx)[ok], ref["nbr_idx"][ok])
+        np.testing.assert_array_equal(host(env.done), ref["done"])
+        H.assert_close(host(env.reward)[ok], ref["reward"][ok], f"reward@{s}", **TIGHT)
+        H.assert_close(host(env.true_reward)[ok], ref["true_reward"][ok], f"true_reward@{s}", **TIGHT)
+        H.assert_close(host(env.z).reshape(ref["z"].shape)[ok], ref["z"][ok], f"z@{s}", **TIGHT)
+        ret += host(env.reward).mean(1); ret_ref += ref["reward"].mean(1)
+    assert checked > 0.99 * E * T and bool(host(env.done).all()) and int(env.t[0]) == T
+    H.assert_close(ret, ret_ref, "episode return", rtol=1e-9, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,G,E,k,c,box", [(256, 256.0, 64, 2, 2, 80.0), (64, 28.0, 512, 2, 2, 26.0), (13, 12.0, 200, 8, 5, 5.0)])
+def test_float32_kernels_against_float64_on_the_device(torch, N, G, E, k, c, box):
+    """The float32 product step judged by the float64 variant evaluated on the SAME float32 post-step state, on the
+    GPU: rewards within the 1e-5 bar, discrete outputs equal on margin-safe envs, z within 1e-5 flat (identical
+    inputs: no coordinate-rounding term even at G = 256)."""
+    from scalable_collision_avoidance_rl_amd import drones
+    rng = np.random.default_rng(N)
+    deltas = np.ones(N) * (2.5 if N == 256 else 1.0)
+    lo = drones(N, 0, [G, G], "O", k_closest=k, deltas=deltas, simplify_zstate=(c == 2), n_envs=E, batched=True,
+                device="cuda:0", seed=1)
+    hi = f64_env(N, G, k, c, deltas, E)
+    pos0 = (G / 2 + (rng.random((E, N, 2)) - 0.5) * box).astype(np.float32)
+    act = rng.uniform(-1, 1, (E, N, 2)).astype(np.float32)
+    lo.set_state(pos0); lo.step(torch.tensor(act, device="cuda:0"))
+    hi.set_state(lo.pos.double(), lo.vel.double())                         # the float32 kernel's own post-step state
+    torch.cuda.synchronize()
+    orc = Oracle(N, [G, G], k, deltas, c == 2, threads=8)
+    safe = orc.margins(host(lo.pos).astype(np.float64)) > H.MARGIN
+    assert safe.mean() > 0.5
+    H.assert_close(host(lo.reward)[safe], host(hi.reward)[safe], "reward f32 vs f64")
+    H.assert_close(host(lo.true_reward)[safe], host(hi.true_reward)[safe], "true reward f32 vs f64")
+    np.testing.assert_array_equal(host(lo.n_coll)[safe], host(hi.n_coll)[safe])
+    np.testing.assert_array_equal(host(lo.nbr_idx)[safe], host(hi.nbr_idx)[safe])
+    H.assert_close(host(lo.z)[safe], host(hi.z)[safe], "z f32 vs f64 (flat 1e-5)")
+
+
+def test_f64_entry_points_validate_arguments(torch):
+    import ctypes as C
+    from scalable_collision_avoidance_rl_amd import _native
+    lib = _native.lib()
+    assert lib.dronesim_step_f64(None, *([None] * 10), 1, None) == _native.EINVAL
+    p = _native.DroneParamsF64(); p.N, p.k, p.c = 5, 9, 2
+    x = torch.zeros(8, dtype=torch.float64, device="cuda:0")
+    ptr = C.c_void_p(x.data_ptr())
+    assert lib.dronesim_observe_f64(C.byref(p), ptr, ptr, None, None, ptr, ptr, None, 1, None) == _native.EINVAL

@@ -80,7 +80,8 @@ def test_params_struct_layout_matches_header():
 def test_episode_structs_match_header():
     """ctypes mirrors of DroneEpisodeAcc / DroneEpisodeCtl (field order, sizes) against include/dronesim.h."""
     header = open(_native.HEADER_PATH).read()
-    for cls, name in ((_native.DroneEpisodeAcc, "DroneEpisodeAcc"), (_native.DroneEpisodeCtl, "DroneEpisodeCtl")):
+    for cls, name in ((_native.DroneEpisodeAcc, "DroneEpisodeAcc"), (_native.DroneEpisodeCtl, "DroneEpisodeCtl"),
+                      (_native.DroneParamsF64, "DroneParamsF64")):
         body = header[header.index("typedef struct %s {" % name):header.index("} %s;" % name)]
         names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|int64_t|uint64_t|float|double|DroneEpisodeAcc)\s*\*?\s*(\w+);", body, re.M)
         assert names == [f[0] for f in cls._fields_], name
