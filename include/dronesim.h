@@ -212,7 +212,7 @@ int dronesim_control(const DroneParams *p, int kind, const float *pos, float *ac
  * reward / true_reward [E][N], n_coll [E] as written by dronesim_step.  One launch, fixed summation order
  * (bit-reproducible).  scratch: DRONESIM_STATS_SCRATCH_DOUBLES doubles of device memory, zero-initialised once by
  * the caller and owned by one accumulator.  Multi-GPU runs all-gather `acc` (the path's only exchange).            */
-#define DRONESIM_STATS_SCRATCH_DOUBLES 193
+#define DRONESIM_STATS_SCRATCH_DOUBLES 769
 int dronesim_episode_stats(const float *reward, const float *true_reward, const int32_t *n_coll, int E, int N,
                            double *acc, double *scratch, void *stream);
 

@@ -21,7 +21,7 @@ MAX_K = 8
 MAX_AGENTS = 1024
 
 # every symbol include/dronesim.h declares (tests check the .so exports all of them)
-STATS_SCRATCH_DOUBLES = 193          # DRONESIM_STATS_SCRATCH_DOUBLES (include/dronesim.h)
+STATS_SCRATCH_DOUBLES = 769          # DRONESIM_STATS_SCRATCH_DOUBLES (include/dronesim.h)
 EPISODE_REDUCE_DOUBLES = 8           # DRONESIM_EPISODE_REDUCE_DOUBLES
 SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_episode_stats", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
            "dronesim_step_ex", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",

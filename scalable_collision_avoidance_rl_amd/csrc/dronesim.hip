@@ -1279,40 +1279,57 @@ __global__ void __launch_bounds__(256) advantage_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------
 // The logged statistic of one step (train_problem.py:98-100: sums of rewards, true rewards and collisions),
 // accumulated in float64 into acc[5] = (sum r, sum true r, sum collisions, agent-steps, env-steps).
-// One launch: every workgroup reduces a slice to three partial sums in `scratch`; the workgroup that
-// arrives last adds the partials IN INDEX ORDER (a fixed summation order: bit-reproducible run to run).
-constexpr int kStatBlocks = 64;
+// One launch: every workgroup reduces a slice to three partial sums in `scratch` (fixed LDS tree); the workgroup that
+// arrives last reduces the partials with the same fixed tree over the block index: bit-reproducible run to run.
+constexpr int kStatBlocks = 256;
 
 __global__ void __launch_bounds__(256) stats_kernel(const float *__restrict__ reward, const float *__restrict__ true_reward,
                                                     const int *__restrict__ n_coll, int E, int N, double *acc,
                                                     double *scratch)
 {
-    __shared__ double sh[3][4];
+    __shared__ double sh[3][256];
     __shared__ bool last;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const size_t n = (size_t)E * N;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) {
-        s0 += (double)reward[i];
-        s1 += (double)true_reward[i];
+    // 16 bytes per lane when the arrays allow it (E * N a multiple of 4 and 16-byte aligned bases), else 4
+    const bool wide = (n & 3) == 0 && ((reinterpret_cast<uintptr_t>(reward) | reinterpret_cast<uintptr_t>(true_reward)) & 15u) == 0;
+    if (wide) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(reward), *t4 = reinterpret_cast<const float4 *>(true_reward);
+        for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n / 4; i += (size_t)gridDim.x * 256) {
+            const float4 a = r4[i], b = t4[i];
+            s0 += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+            s1 += ((double)b.x + (double)b.y) + ((double)b.z + (double)b.w);
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) {
+            s0 += (double)reward[i];
+            s1 += (double)true_reward[i];
+        }
     }
     for (int e = blockIdx.x * 256 + tid; e < E; e += gridDim.x * 256) s2 += (double)n_coll[e];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if (lane == 0) { sh[0][wave] = s0; sh[1][wave] = s1; sh[2][wave] = s2; }
+    sh[0][tid] = s0; sh[1][tid] = s1; sh[2][tid] = s2;
     __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {                       // fixed tree: the order depends on nothing but (E, N)
+        if (tid < w) { sh[0][tid] += sh[0][tid + w]; sh[1][tid] += sh[1][tid + w]; sh[2][tid] += sh[2][tid + w]; }
+        __syncthreads();
+    }
     unsigned *ticket = reinterpret_cast<unsigned *>(scratch + 3 * kStatBlocks);
     if (tid == 0) {
-        for (int k = 0; k < 3; ++k) scratch[k * kStatBlocks + blockIdx.x] = (sh[k][0] + sh[k][1]) + (sh[k][2] + sh[k][3]);
+        for (int k = 0; k < 3; ++k) scratch[k * kStatBlocks + blockIdx.x] = sh[k][0];
         __threadfence();
         last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (last && tid < 3) {
-        __threadfence();
-        double t = 0.0;
-        for (int b = 0; b < (int)gridDim.x; ++b) t += __builtin_nontemporal_load(scratch + tid * kStatBlocks + b);
-        acc[tid] += t;
+    if (last) {                                               // the workgroup that arrives last adds the partials,
+        __threadfence();                                      // again as a fixed tree over the block index
+        for (int k = 0; k < 3; ++k) sh[k][tid] = tid < (int)gridDim.x ? __builtin_nontemporal_load(scratch + k * kStatBlocks + tid) : 0.0;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) { sh[0][tid] += sh[0][tid + w]; sh[1][tid] += sh[1][tid + w]; sh[2][tid] += sh[2][tid + w]; }
+            __syncthreads();
+        }
+        if (tid < 3) acc[tid] += sh[tid][0];
         if (tid == 0) { acc[3] += (double)E * N; acc[4] += (double)E; *ticket = 0u; }
     }
 }

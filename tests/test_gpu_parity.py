@@ -204,7 +204,11 @@ def test_step_matches_oracle(torch, cfg):
     ref = orc.observe(p1, act.astype(np.float64))
     margin = np.minimum(orc.margins(p1), orc.margins(pos))
     safe = margin > H.MARGIN
-    assert safe.mean() > 0.3, f"only {safe.mean():.2f} of envs are margin-safe"
+    # the margin filter must not hollow the comparison out: fractions measured with the oracle for these seeds are
+    # 0.92 .. 1.0 at the BASELINE shapes; three edge shapes sit lower (Delta = d_hat ties: 0.51; N = 300 / 700 at
+    # E = 24 / 5: 0.88 / 0.6)
+    floor = {"n5_c5_nodelta": 0.45, "n300_k2_c5": 0.8, "n700_k4": 0.55}.get(name, 0.9)
+    assert safe.mean() >= floor, f"only {safe.mean():.3f} of envs are margin-safe"
     np.testing.assert_array_equal(host(res.finished)[safe], ref_step["done"][safe])
     np.testing.assert_array_equal(ref["nbr_idx"][safe], ref_step["nbr_idx"][safe])   # same decisions either way
     # tied (clipped) entries are ordered by lowest index on both sides (oracle = stable argsort),
@@ -222,6 +226,66 @@ def test_step_matches_oracle(torch, cfg):
     assert np.all(host(env.true_reward) <= host(env.reward) + 1e-6)                  # log terms are >= 0
     z, nbi, nbc = env.get_local_states()
     np.testing.assert_array_equal(host(nbc), cnt)
+
+
+def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch):
+    """BASELINE configs[4] as it is stated: n = 256 agents x 512 envs (one GPU's shard of 4096), Delta = 2.5, G = 256,
+    actions from a continuous Gaussian policy -- the batched per-agent NormalActorNN (6 -> 400 -> (200 | 200) ->
+    tanh mu[2] | sigmoid var[2], utils.py:55-117) evaluated on the env's own observation every step.
+    Policy outputs vs a float64 torch evaluation of the SAME two-head networks (1e-5 bar); the sampled actions are
+    mu + sqrt(var) * eps with eps ~ N(0, 1) (utils.py:110-117); env outputs vs the oracle on the sampled actions."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP, stack_reference_modules
+    N, G, E, T = 256, 256.0, 512, 3
+    deltas = np.ones(N) * 2.5
+    env = make_env(N, G, 2, 2, deltas, E, seed=5)
+    orc = Oracle(N, [G, G], 2, deltas, True, threads=8)
+    assert orc.d_hat.min() == pytest.approx(2.62) and np.array_equal(orc.delta, deltas)       # Delta is effective
+    g = torch.Generator().manual_seed(77)
+    lin = lambda i, o, sc: _L(((torch.rand(i, o, generator=g) * 2 - 1) * sc).numpy(), ((torch.rand(o, generator=g) * 2 - 1) * sc).numpy())
+    mods = []
+    for _ in range(N):                                      # per-agent networks of the reference's architecture
+        m = _M()
+        m.input_layer, m.hidden_layer1, m.hidden_layer2 = lin(6, 400, 0.08), lin(400, 200, 0.08), lin(400, 200, 0.08)
+        m.out_1, m.out_2 = lin(200, 2, 0.15), lin(200, 2, 0.15)
+        mods.append(m)
+    pol = BatchedMLP.from_normal_actor(mods, seed=9)
+    assert (pol.h1, pol.h2, pol.nout) == (400, 400, 4)
+    W = lambda name: torch.stack([getattr(m, name).weight.double() for m in mods])          # [N, out, in]
+    B = lambda name: torch.stack([getattr(m, name).bias.double() for m in mods])
+
+    def reference(z):                                       # float64, two heads evaluated separately (utils.py:89-108)
+        zd = z.double().cpu()
+        l1 = torch.relu(torch.einsum("end,nhd->enh", zd, W("input_layer")) + B("input_layer"))
+        h1 = torch.relu(torch.einsum("enh,nkh->enk", l1, W("hidden_layer1")) + B("hidden_layer1"))
+        h2 = torch.relu(torch.einsum("enh,nkh->enk", l1, W("hidden_layer2")) + B("hidden_layer2"))
+        mu = torch.tanh(torch.einsum("enk,nok->eno", h1, W("out_1")) + B("out_1"))
+        var = torch.sigmoid(torch.einsum("enk,nok->eno", h2, W("out_2")) + B("out_2"))
+        return torch.cat([mu, var], -1).numpy()
+
+    eps_all = []
+    for s in range(T):
+        z = env.z.clone()
+        act, idx, out = pol.sample_action(env.z, env=env, return_outputs=True)
+        torch.cuda.synchronize()
+        assert idx is None and tuple(act.shape) == (E, N, 2)
+        ref_out = reference(z)
+        H.assert_close(host(out), ref_out, f"policy (mu, var) @ step {s}")
+        eps_all.append((host(act).astype(np.float64) - ref_out[..., :2]) / np.sqrt(ref_out[..., 2:]))
+        pos0 = host(env.pos).astype(np.float64); vel0 = host(env.vel).astype(np.float64); t0 = host(env.t).copy()
+        res = env.step(act)
+        torch.cuda.synchronize()
+        a64 = host(act).astype(np.float64)
+        ref_step = orc.step(pos0, vel0, t0, a64)            # pos0 is integrated in place
+        H.assert_close(host(env.pos), pos0, f"pos @ step {s}", atol=float(np.spacing(np.float32(G))), rtol=2e-7)
+        p1 = host(env.pos).astype(np.float64)
+        ref = orc.observe(p1, a64)
+        safe = np.minimum(orc.margins(p1), orc.margins(pos0)) > H.MARGIN
+        assert safe.mean() >= 0.9
+        np.testing.assert_array_equal(host(res.finished)[safe], ref_step["done"][safe])
+        check_outputs(env, res, ref, safe, 2, None, f"C5 step {s} ")
+    eps = np.concatenate([e.ravel() for e in eps_all])
+    assert abs(eps.mean()) < 0.01 and abs(eps.var() - 1.0) < 0.01 and abs((eps ** 3).mean()) < 0.03
+    assert abs((eps ** 4).mean() - 3.0) < 0.08                                    # Gaussian, not just unit variance
 
 
 def test_observe_matches_oracle_and_mask(torch):
@@ -329,6 +393,37 @@ def test_reset_matches_oracle_bit_exact_and_shards(torch):
             part = make_env(N, G, 2, 2, np.ones(N), E, seed=77, rank=r, world_size=3)
             assert torch.equal(part.pos, full.pos[part.env_lo:part.env_hi])
             assert torch.equal(part.z, full.z[part.env_lo:part.env_hi])
+
+
+def test_reset_sampling_is_uniform_over_the_lattice(torch):
+    """Statistical check of the reset stream (the reference draws random.sample over the lattice nodes,
+    drone_env.py:204: every node equally likely, no node twice in an env): chi-square of the node occupancy over
+    20 resets x 4096 envs, of one agent's marginal, and of the joint cell of two agents on a coarsened lattice."""
+    from scalable_collision_avoidance_rl_amd import lattice_divisions
+    N, G, E, R = 5, 5.0, 4096, 20
+    env = make_env(N, G, 2, 2, np.ones(N), E, seed=2024)
+    dx, dy = lattice_divisions([G, G])
+    M = dx * dy
+    occ = np.zeros(M); a0 = np.zeros(M); joint = np.zeros((4, 4))
+    for r in range(R):
+        if r:
+            env.reset(renew_obstacles=False)
+        p = host(env.pos)
+        node = np.rint(p[..., 0] / 0.22).astype(np.int64) * dy + np.rint(p[..., 1] / 0.22).astype(np.int64)
+        assert all(len(set(row)) == N for row in node.tolist())
+        occ += np.bincount(node.ravel(), minlength=M); a0 += np.bincount(node[:, 0], minlength=M)
+        q = lambda v: np.minimum(v * 4 // M, 3)
+        np.add.at(joint, (q(node[:, 1]), q(node[:, 3])), 1)
+
+    def chi2(obs, exp):
+        return float(((obs - exp) ** 2 / exp).sum())
+    # chi-square with M - 1 dof: mean M - 1, sd sqrt(2 (M - 1)); 5 sigma bands
+    for name, obs in (("occupancy", occ), ("agent 0", a0)):
+        x = chi2(obs, obs.sum() / M)
+        assert abs(x - (M - 1)) < 5 * np.sqrt(2 * (M - 1)), (name, x, M - 1)
+    rows = joint.sum(1, keepdims=True); cols = joint.sum(0, keepdims=True)
+    x = chi2(joint, rows * cols / joint.sum())                 # independence of two agents' coarse cells, 9 dof
+    assert x < 9 + 6 * np.sqrt(18), x
 
 
 # ------------------------------------------------------------------------------- rollout / determinism
