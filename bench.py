@@ -226,6 +226,10 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter(); graph.replay(); torch.cuda.synchronize()
         one = max(time.perf_counter() - t0, 1e-6)
+        if world > 1:                               # every rank must replay (and exchange) the same number of times
+            o = torch.tensor([one], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(o, op=dist.ReduceOp.MIN)
+            one = float(o.item())
         repeats = max(1, int(np.ceil(1.2 * args.min_seconds / one)))
     else:
         repeats = 1
