@@ -99,6 +99,7 @@ struct KArgs {
     int *episode;
     float *act_out;                 // rand_act: optional record of the actions drawn, [T][E][N][2]
     int lds_tail;                   // byte offset of the bookkeeping regions behind the bucket tables
+    int samp_tbl, samp_shift;       // in-kernel reset: entries of the sampling table per env slot (2^k >= 2 N), 32 - k
 };
 
 // @phase h_nbr_list
@@ -405,8 +406,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     const int W = BLOCKGEO ? nwaves : 1;
     const bool use_bucket = !FAR && !SYM && (BLOCKGEO || a.bucket != 0);                   // launch-uniform
     unsigned long long *sbt = sbt_all + (size_t)slot * (2 * kCells) * W;                   // this lane's env
-    // tail (episode bookkeeping): per-wave partial reward sums [nwaves][2], then the lattice-sampling scratch of the
-    // in-kernel reset [epb][N] x (settled node, proposal)
+    // tail (episode bookkeeping): per-wave partial reward sums [nwaves][2], then the sampling tables of the in-kernel
+    // reset, [epb][samp_tbl] x (node, owner)
     float *spart = reinterpret_cast<float *>(smem + a.lds_tail);
     int2 *ssamp = reinterpret_cast<int2 *>(spart + 2 * ((nwaves + 1) & ~1));
 
@@ -557,7 +558,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     npool += __builtin_popcountll(m);
                 }
             }
-            const bool crowded = __builtin_amdgcn_ballot_w64(npool > kBucketMax) != 0ull;
+            const bool crowded = __builtin_expect(__builtin_amdgcn_ballot_w64(npool > kBucketMax) != 0ull, 0);
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) {
                 if (w < W) {
@@ -646,7 +647,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     unsigned long long pool = (sbucket[cx - 1].x | sbucket[cx].x | sbucket[cx + 1].x) &
                                               (sbucket[cy - 1].y | sbucket[cy].y | sbucket[cy + 1].y) & ~self;
                     unsigned long long hits = 0ull;          // bit j: agent j is inside the list radius
-                    if (__builtin_amdgcn_ballot_w64(__builtin_popcountll(pool) > kBucketMax) == 0ull) {
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_popcountll(pool) > kBucketMax) == 0ull, 1)) {
                         // (b) exact test of the few candidates
                         while (pool) {
                             const int j = __builtin_ctzll(pool);
@@ -920,7 +921,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 rs = valid && sred[2 * slot + 1] != 0;
                 any_rs = WL ? (__builtin_amdgcn_ballot_w64(rs) != 0ull) : (__syncthreads_or(rs ? 1 : 0) != 0);
             }
-            if (any_rs) {
+            if (__builtin_expect(any_rs, 0)) {                // once per episode and env: out of line
                 if (!rand_act && rs)                          // the episode counter is only needed here: read it now (past
                     epi = (uint32_t)__builtin_nontemporal_load(a.episode + env);   // L1: an earlier reset of this launch wrote it)
                 if (rs && agent == 0) {
@@ -941,32 +942,37 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         accw = make_uint4(0u, 0u, accw.z + 1u, accw.w);           // episodes += 1
                     }
                 }
-                int2 *mine = ssamp + (size_t)slot * N;
+                // ---- N distinct lattice nodes, the acceptance rule of reset_kernel (an unsettled agent settles on its
+                // proposal iff no settled agent holds that node and no lower-index agent proposed it this round), found
+                // through an open-addressing table in LDS instead of an O(N) scan per agent: settled agents enter their
+                // node as blockers (owner -1), proposers enter theirs with owner = min(agent index); a proposer wins iff
+                // it owns its entry.  Keys are compared exactly, so the draw is the one reset_kernel / the oracle make.
+                const int nt = a.samp_tbl;                        // entries per env slot, a power of two >= 2 N
+                int2 *tbl = ssamp + (size_t)slot * nt;
                 int node = -1;
                 uint32_t round = 0;
                 bool more;
                 do {
-                    int prop = -1;
+                    if (rs)
+                        for (int o = agent; o < nt; o += N) tbl[o] = make_int2(-1, 0x7fffffff);
+                    group_sync<WL>();
+                    int prop = node, h = 0;
                     if (rs) {
                         if (node < 0)
                             prop = (int)__umulhi(philox4x32_10_word0((uint32_t)agent, round, gid, epi, a.key0, a.key1), a.lat_M);
-                        mine[agent] = make_int2(node, prop);
+                        h = (int)(((uint32_t)prop * 0x9E3779B1u) >> a.samp_shift);
+                        for (;;) {                                                // linear probing, load factor <= 1/2
+                            const int old = atomicCAS(&tbl[h].x, -1, prop);
+                            if (old == -1 || old == prop) break;
+                            h = (h + 1) & (nt - 1);
+                        }
+                        atomicMin(&tbl[h].y, node >= 0 ? -1 : agent);
                     }
                     group_sync<WL>();
-                    if (rs && node < 0) {
-                        bool clash = false;
-#pragma nounroll
-                        for (int j = 0; j < N; ++j) {
-                            const int2 o = mine[j];
-                            const bool held = o.x >= 0 && o.x == prop;                // held since an earlier round
-                            const bool lower = o.x < 0 && j < agent && o.y == prop;   // lower index wins the round
-                            clash = clash || held || lower;
-                        }
-                        if (!clash) node = prop;
-                    }
+                    if (rs && node < 0 && tbl[h].y == agent) node = prop;
                     const bool left = rs && node < 0;
                     more = WL ? (__builtin_amdgcn_ballot_w64(left) != 0ull) : (__syncthreads_or(left ? 1 : 0) != 0);
-                    if (WL) group_sync<true>();                   // this round's reads before the next round's writes
+                    if (WL) group_sync<true>();                   // this round's reads before the next round's clearing
                     ++round;
                 } while (more && round < (1u << 20));
                 if (rs) {
@@ -986,15 +992,42 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     for (int s2 = 0; s2 <= K; ++s2) list[s2] = ~0ull;
                     list[0] = nbr_key(dii, agent);
                     in_range = ((dii <= delta_i) ? 1 : 0) - 1;
+                    if (WMAX <= 4) {
+                        // one cheap scan builds this agent's partner mask, then it walks its own bits: the expensive
+                        // pair arithmetic runs max-over-lanes(partners) times, not once per agent of the env
+                        unsigned long long bits[WMAX];
+#pragma unroll
+                        for (int w = 0; w < WMAX; ++w) {
+                            bits[w] = 0ull;
+                            const int jn = min(64, N - 64 * w);
 #pragma nounroll
-                    for (int j = 0; j < N; ++j) {                 // ascending order, like every other path
-                        if (j == agent) continue;
-                        if (!FAR) {
-                            const float2 pj = spos_env[j];
-                            const float dx = xi - pj.x, dy = yi - pj.y;
-                            if (!(fmaf(dy, dy, dx * dx) < thr)) continue;
+                            for (int u = 0; u < jn; ++u) {
+                                const float2 pj = spos_env[64 * w + u];
+                                const float dx = xi - pj.x, dy = yi - pj.y;
+                                const bool hit = FAR || fmaf(dy, dy, dx * dx) < thr;
+                                bits[w] |= (hit && 64 * w + u != agent) ? (1ull << u) : 0ull;
+                            }
                         }
-                        visit(j);
+#pragma unroll
+                        for (int w = 0; w < WMAX; ++w) {
+                            unsigned long long m = bits[w];
+                            while (m) {                           // ascending order, like every other path
+                                const int u = __builtin_ctzll(m);
+                                m &= m - 1ull;
+                                visit(64 * w + u);
+                            }
+                        }
+                    } else {
+#pragma nounroll
+                        for (int j = 0; j < N; ++j) {             // ascending order, like every other path
+                            if (j == agent) continue;
+                            if (!FAR) {
+                                const float2 pj = spos_env[j];
+                                const float dx = xi - pj.x, dy = yi - pj.y;
+                                if (!(fmaf(dy, dy, dx * dx) < thr)) continue;
+                            }
+                            visit(j);
+                        }
                     }
                     const float zx = xi - xFx, zy = yi - xFy;
                     const float gsc = __builtin_amdgcn_rsqf(fmaf(zy, zy, zx * zx)) * delta_i * a.ghost_factor;
@@ -1052,7 +1085,7 @@ namespace {
 // (restated integer-exactly on the CPU in oracle/drone_oracle.c:oracle_reset).
 
 struct RArgs {
-    int N, E, P, epb, div_y;
+    int N, E, P, epb, div_y, nt, shift;     // nt: sampling-table entries per env (2^k >= 2 N), shift = 32 - k
     uint32_t M, key0, key1;
     long long env_base;
     float pitch;
@@ -1066,7 +1099,7 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N;
-    int2 *sst = reinterpret_cast<int2 *>(smem);            // [epb][N] (settled node or -1, proposal of this round or -1)
+    int2 *sst = reinterpret_cast<int2 *>(smem);            // [epb][nt] open-addressing table of (node, owner)
     const int tid = threadIdx.x;
     int slot, agent;
     bool valid;
@@ -1084,32 +1117,36 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
     if (valid && a.mask != nullptr) valid = a.mask[env] != 0;
     const uint32_t gid = (uint32_t)(a.env_base + env);
     const uint32_t epi = valid ? (uint32_t)a.episode[env] : 0u;   // resets this env has seen so far
-    int2 *mine = sst + (size_t)slot * N;
+    // Round r: unsettled agent i proposes node mulhi(philox(i, r, env, episode), M) and settles on it iff no settled
+    // agent holds that node and no lower-index agent proposed it this round.  The rule is evaluated through an
+    // open-addressing table per env (2^k >= 2 N entries, keys compared exactly): settled agents enter their node as
+    // blockers (owner -1), proposers enter theirs with owner = min(agent index); a proposer wins iff it owns its entry.
+    const int nt = a.nt;
+    int2 *tbl = sst + (size_t)slot * nt;
 
     int node = -1;
     int remaining;
     uint32_t round = 0;
     do {
-        int cand = -1;
+        if (valid)
+            for (int o = agent; o < nt; o += N) tbl[o] = make_int2(-1, 0x7fffffff);
+        __syncthreads();
+        int cand = node, h = 0;
         if (valid) {
             if (node < 0) {
                 const uint32_t w = philox4x32_10_word0((uint32_t)agent, round, gid, epi, a.key0, a.key1);
                 cand = (int)__umulhi(w, a.M);
             }
-            mine[agent] = make_int2(node, cand);
+            h = (int)(((uint32_t)cand * 0x9E3779B1u) >> a.shift);
+            for (;;) {                                                // linear probing, load factor <= 1/2
+                const int old = atomicCAS(&tbl[h].x, -1, cand);
+                if (old == -1 || old == cand) break;
+                h = (h + 1) & (nt - 1);
+            }
+            atomicMin(&tbl[h].y, node >= 0 ? -1 : agent);
         }
         __syncthreads();
-        if (valid && node < 0) {
-            bool clash = false;                                       // branch-free so the LDS reads pipeline
-#pragma unroll 8
-            for (int j = 0; j < N; ++j) {
-                const int2 o = mine[j];
-                const bool held = o.x >= 0 && o.x == cand;            // held since an earlier round
-                const bool lower = o.x < 0 && j < agent && o.y == cand;   // lower index wins the round
-                clash = clash || held || lower;
-            }
-            if (!clash) node = cand;
-        }
+        if (valid && node < 0 && tbl[h].y == agent) node = cand;
         remaining = __syncthreads_count(valid && node < 0);
         ++round;
     } while (remaining > 0 && round < (1u << 20));
@@ -1424,11 +1461,19 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k)
     return b;
 }
 
-// bookkeeping regions behind the bucket tables: [nwaves rounded to even][2] floats + [epb][N] int2
+// entries of the in-kernel reset's sampling table per env slot: the power of two >= 2 N
+int samp_table_entries(int N)
+{
+    int nt = 4;
+    while (nt < 2 * N) nt <<= 1;
+    return nt;
+}
+
+// bookkeeping regions behind the bucket tables: [nwaves rounded to even][2] floats + [epb][table] int2
 size_t drone_lds_tail_bytes(const Geometry &g, int N)
 {
     const size_t nwaves = (size_t)g.threads / kWave;
-    return sizeof(float) * 2 * ((nwaves + 1) & ~(size_t)1) + sizeof(int2) * (size_t)g.epb * N;
+    return sizeof(float) * 2 * ((nwaves + 1) & ~(size_t)1) + sizeof(int2) * (size_t)g.epb * samp_table_entries(N);
 }
 
 int check_params(const DroneParams *p, int E)
@@ -1566,6 +1611,8 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     g.lds = drone_lds_bytes(g, p->N, p->k);
     a.lds_tail = (int)g.lds;
     g.lds += drone_lds_tail_bytes(g, p->N);
+    a.samp_tbl = samp_table_entries(p->N);
+    a.samp_shift = 32 - __builtin_ctz((unsigned)a.samp_tbl);
     if (g.lds > 160 * 1024) return fail(DRONESIM_EUNSUPPORTED, "n_agents x k_closest too large for the 160 KiB LDS tile");
     a.N = p->N; a.c = p->c; a.max_steps = p->max_steps; a.E = E;
     a.P = g.P; a.epb = g.epb;
@@ -1745,7 +1792,9 @@ int reset_impl(const DroneParams *p, int div_x, int div_y, float pitch, uint64_t
     a.key1 = (uint32_t)(seed >> 32);
     a.env_base = env_base; a.pitch = pitch; a.mask = mask;
     a.pos = pos; a.vel = vel; a.t = t; a.episode = episode; a.node_out = node_out; a.acc = acc;
-    const size_t lds = sizeof(int) * 2 * (size_t)g.epb * p->N;
+    a.nt = samp_table_entries(p->N);
+    a.shift = 32 - __builtin_ctz((unsigned)a.nt);
+    const size_t lds = sizeof(int2) * (size_t)g.epb * a.nt;
     hipLaunchKernelGGL(reset_kernel, dim3(g.blocks), dim3(g.threads), lds, static_cast<hipStream_t>(stream), a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
