@@ -126,6 +126,71 @@ __device__ __forceinline__ void nbr_insert(unsigned long long (&list)[K + 1], un
 }
 
 // @phase h_nan_to_num
+// The first K+1 entries of a stable argsort of row i (drone_env.py:338): entry 0 starts as the agent itself.
+//   ASC = false: general form, one 64-bit key per entry, valid for any visiting order (the relative-window scans visit
+//                partner (i + r) mod N for r = 1, 2, ...).
+//   ASC = true:  partners arrive in ASCENDING agent index (bucket filter, symmetric filter, the in-kernel reset's
+//                re-observation).  A new partner then follows every earlier partner of equal distance, so a strict
+//                float compare orders it exactly; only the agent's own entry (index i, sitting between the j < i and
+//                the j > i) needs the index, and a partner can only reach it with d <= d_ii -- exactly coincident
+//                agents, or a larger partner overlapping a smaller agent's centre.  That case takes the general
+//                insertion, wave-uniformly; everything else inserts behind entry 0 with 5 instructions per stage
+//                instead of 8 on 64-bit keys.
+template <int K, bool ASC> struct NbrList;
+template <int K> struct NbrList<K, false> {
+    unsigned long long key[K + 1];
+    __device__ __forceinline__ void init(float dii, int agent)
+    {
+#pragma unroll
+        for (int s = 0; s <= K; ++s) key[s] = ~0ull;
+        key[0] = nbr_key(dii, agent);
+    }
+    __device__ __forceinline__ void insert(float d, int j, float) { nbr_insert<K>(key, nbr_key(d, j)); }
+    __device__ __forceinline__ unsigned index(int kth) const { return (unsigned)key[kth]; }
+};
+template <int K> struct NbrList<K, true> {
+    float d[K + 1];
+    unsigned j[K + 1];
+    __device__ __forceinline__ void init(float dii, int agent)
+    {
+#pragma unroll
+        for (int s = 0; s <= K; ++s) { d[s] = __builtin_inff(); j[s] = ~0u; }
+        d[0] = dii; j[0] = (unsigned)agent;
+    }
+    __device__ __forceinline__ void insert(float dn, int jn, float dii)
+    {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dn > dii)) != 0ull, 0)) {
+            // general insertion on (d, j) keys over all K+1 entries (NaN distances order like their bit patterns)
+            unsigned long long key = nbr_key(dn, jn);
+#pragma unroll
+            for (int s = 0; s <= K; ++s) {
+                const unsigned long long cur = j[s] == ~0u && d[s] == __builtin_inff() ? ~0ull : nbr_key(d[s], (int)j[s]);
+                const bool lt = key < cur;
+                const unsigned long long out = lt ? key : cur;
+                key = lt ? cur : key;
+                if (out == ~0ull) { d[s] = __builtin_inff(); j[s] = ~0u; }
+                else {
+                    const unsigned o = (unsigned)(out >> 32);
+                    d[s] = __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+                    j[s] = (unsigned)out;
+                }
+            }
+            return;
+        }
+        float kd = dn;
+        unsigned kj = (unsigned)jn;
+#pragma unroll
+        for (int s = 1; s <= K; ++s) {
+            const bool lt = kd < d[s];
+            const float cd = d[s];
+            const unsigned cj = j[s];
+            d[s] = lt ? kd : cd; j[s] = lt ? kj : cj;
+            kd = lt ? cd : kd; kj = lt ? cj : kj;
+        }
+    }
+    __device__ __forceinline__ unsigned index(int kth) const { return j[kth]; }
+};
+
 __device__ __forceinline__ float nan_to_num_f32(float x)   // np.nan_to_num, drone_env.py:287-288
 {
     if (x != x) return 0.0f;
@@ -511,12 +576,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         int nbv[K + 1];
         float s_all = 0.f, s_msk = 0.f;
         int ncoll = 0;
-        unsigned long long list[K + 1];
-#pragma unroll
-        for (int s = 0; s <= K; ++s) list[s] = ~0ull;
+        // partners reach pass 2 in ascending agent order on every path of these geometries (bucket / symmetric filter)
+        constexpr bool ASC = SYM || (BLOCKGEO && !FAR);
+        NbrList<K, ASC> list;
         // self entry: d_ii = min(-2 l_i, dhat_i), ratio 1 -> log 0, never a collision (:323-325)
         const float dii = fminf(-li - li, dhat);
-        list[0] = nbr_key(dii, agent);
+        list.init(dii, agent);
         int in_range = ((dii <= delta_i) ? 1 : 0) - 1;        // :346 (N_delta[i,i] uses Delta_i), minus itself
 
         // @phase pass2_visit
@@ -533,7 +598,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             s_msk += pt.inm ? pt.lg : 0.0f;                                   // :282
             ncoll += pt.coll ? 1 : 0;                                         // :284
             in_range += pt.inm ? 1 : 0;
-            nbr_insert<K>(list, nbr_key(pt.d, j));                            // :338
+            list.insert(pt.d, j, dii);                                        // :338
         };
 
         // @phase filter_generic2
@@ -757,7 +822,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             have[0] = true;
 #pragma unroll
             for (int kth = 1; kth <= K; ++kth) {
-                const unsigned j = (unsigned)list[kth];
+                const unsigned j = list.index(kth);
                 have[kth] = j < (unsigned)N;
                 const bool real = kth <= in_range && have[kth];               // :362
                 float rx = ghx, ry = ghy;
@@ -781,7 +846,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         if (kth == 0) {
                             row[2] = vxi; row[3] = vyi; row[4] = li;          // :355
                         } else if (have[kth]) {                               // :367 / :385
-                            const unsigned j = (unsigned)list[kth];
+                            const unsigned j = list.index(kth);
                             float2 vj;
                             if (rand_act) {                            // counter-based stream: any lane can
                                 uint32_t o[4];                                // restate any agent's action
@@ -988,9 +1053,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 group_sync<WL>();
                 __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this wave's earlier z / Ni / state stores
                 if (rs) {                                         //           have landed before they are overwritten
-#pragma unroll
-                    for (int s2 = 0; s2 <= K; ++s2) list[s2] = ~0ull;
-                    list[0] = nbr_key(dii, agent);
+                    list.init(dii, agent);
                     in_range = ((dii <= delta_i) ? 1 : 0) - 1;
                     if (WMAX <= 4) {
                         // one cheap scan builds this agent's partner mask, then it walks its own bits: the expensive
@@ -1035,7 +1098,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     int *nb = a.nbr_idx + (so + wga0 + lane) * (size_t)(K + 1);
 #pragma unroll
                     for (int kth = 0; kth <= K; ++kth) {
-                        const unsigned j = (unsigned)list[kth];
+                        const unsigned j = list.index(kth);
                         const bool hv = kth == 0 || j < (unsigned)N;
                         const bool real = kth == 0 || (kth <= in_range && hv);
                         float rx = kth == 0 ? zx : zx * gsc, ry = kth == 0 ? zy : zy * gsc;
@@ -1610,9 +1673,11 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     Geometry g = geometry(p->N, E);
     g.lds = drone_lds_bytes(g, p->N, p->k);
     a.lds_tail = (int)g.lds;
-    g.lds += drone_lds_tail_bytes(g, p->N);
-    a.samp_tbl = samp_table_entries(p->N);
-    a.samp_shift = 32 - __builtin_ctz((unsigned)a.samp_tbl);
+    if (a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0) {   // the episode layer's regions: only when it is in use
+        g.lds += drone_lds_tail_bytes(g, p->N);
+        a.samp_tbl = samp_table_entries(p->N);
+        a.samp_shift = 32 - __builtin_ctz((unsigned)a.samp_tbl);
+    }
     if (g.lds > 160 * 1024) return fail(DRONESIM_EUNSUPPORTED, "n_agents x k_closest too large for the 160 KiB LDS tile");
     a.N = p->N; a.c = p->c; a.max_steps = p->max_steps; a.E = E;
     a.P = g.P; a.epb = g.epb;
