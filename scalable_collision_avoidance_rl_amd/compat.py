@@ -36,13 +36,32 @@ class _ReferencePickle:
     __name__ = "reference_pickle"
 
     class Unpickler(pickle.Unpickler):
+        """Resolves ONLY what such a file legitimately names: torch's tensor / storage rebuild helpers and
+        `torch.nn` modules, `collections.OrderedDict`, NumPy's array reconstruction, builtins' plain containers, and
+        the reference's own classes (as stand-ins).  Anything else raises instead of being imported -- a pickle is
+        code, and a file from an untrusted source must still not be opened with this loader."""
+        _ALLOWED_PREFIXES = ("torch._utils", "torch.nn.", "torch.storage", "torch._tensor", "torch.serialization",
+                             "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric")
+        _ALLOWED = {("collections", "OrderedDict"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "list"),
+                    ("builtins", "dict"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"),
+                    ("builtins", "complex"), ("builtins", "bool"), ("builtins", "slice"), ("builtins", "range"),
+                    ("numpy", "ndarray"), ("numpy", "dtype"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+                    ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"), ("torch.optim.adam", "Adam"),
+                    ("collections", "defaultdict"), ("collections", "deque"), ("_codecs", "encode")}
+
         def find_class(self, module, name):
             if module in _REFERENCE_MODULES:
                 try:
                     return super().find_class(module, name)          # the real class, if the caller imported it
                 except (ImportError, AttributeError):
                     return _standin(module, name)
-            return super().find_class(module, name)
+            if module == "__builtin__":                              # protocol-2 spelling of builtins
+                module = "builtins"
+            if (module, name) in self._ALLOWED or module.startswith(self._ALLOWED_PREFIXES) or \
+                    (module == "torch" and name.endswith(("Storage", "Tensor"))):
+                return super().find_class(module, name)
+            raise pickle.UnpicklingError(f"{module}.{name} is not something a saved list of the reference's networks "
+                                         "contains; refusing to import it")
 
     @staticmethod
     def load(f, **kw):
@@ -54,7 +73,8 @@ class _ReferencePickle:
 
 def load_reference_modules(path):
     """List of per-agent objects from one of the reference's ``*-A2Cactors.pth`` / ``*-A2Ccritics.pth`` /
-    ``*-actors.pth`` / ``*-critics.pth`` files (CPU tensors)."""
+    ``*-actors.pth`` / ``*-critics.pth`` files (CPU tensors).  The unpickler imports nothing outside torch / NumPy /
+    containers (see `_ReferencePickle.Unpickler`); still, only open files you trust."""
     import torch
     return torch.load(path, map_location="cpu", pickle_module=_ReferencePickle, weights_only=False)
 

@@ -125,7 +125,6 @@ __device__ __forceinline__ void nbr_insert(unsigned long long (&list)[K + 1], un
     }
 }
 
-// @phase h_nan_to_num
 // The first K+1 entries of a stable argsort of row i (drone_env.py:338): entry 0 starts as the agent itself.
 //   ASC = false: general form, one 64-bit key per entry, valid for any visiting order (the relative-window scans visit
 //                partner (i + r) mod N for r = 1, 2, ...).
@@ -191,6 +190,7 @@ template <int K> struct NbrList<K, true> {
     __device__ __forceinline__ unsigned index(int kth) const { return j[kth]; }
 };
 
+// @phase h_nan_to_num
 __device__ __forceinline__ float nan_to_num_f32(float x)   // np.nan_to_num, drone_env.py:287-288
 {
     if (x != x) return 0.0f;

@@ -109,3 +109,22 @@ def test_figures_render_from_trajectories(tmp_path):
     assert compat.show_state(env, traj[0]) is not None
     full = compat.animate_trajectory(env, traj, ztraj, np.ones(3) * 0.5, episode=0, name="t", folder=str(tmp_path), fps=10)
     assert os.path.getsize(full) > 1000
+
+
+def test_loader_refuses_classes_outside_its_allowlist(tmp_path):
+    """A saved-networks file is a pickle: the loader resolves torch / NumPy / container names and the reference's own
+    classes only; anything else (here: os.system smuggled in through __reduce__) raises instead of being imported."""
+    import pickle
+
+    import torch
+
+    from scalable_collision_avoidance_rl_amd import compat
+
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("true",))
+    path = str(tmp_path / "evil.pth")
+    torch.save([Evil()], path)
+    with pytest.raises(pickle.UnpicklingError, match="refusing"):
+        compat.load_reference_modules(path)

@@ -51,7 +51,8 @@ def main():
     raw_f = sum(fk) / len(fk) * 1024
     raw_w = sum(wk) / len(wk) * 1024
     cf = cal["b64"]["fetch_ratio_20MiB"]; cw = cal["b64"]["write_ratio_20MiB"]
-    alg_read, alg_write = 16 * N * E + 4 * E, 60 * N * E + 9 * E
+    layer = not os.environ.get("PLAIN")            # episode layer: + 32 B read and 32 B written per env (the record)
+    alg_read, alg_write = 16 * N * E + (4 + (32 if layer else 0)) * E, 60 * N * E + (9 + (32 if layer else 0)) * E
     res.update(step_kernel_launches=len(fk), raw_fetch_bytes_per_launch=raw_f, raw_write_bytes_per_launch=raw_w,
                corrected_fetch_bytes_per_launch=raw_f / cf, corrected_write_bytes_per_launch=raw_w / cw,
                traffic_bytes_per_launch=raw_f / cf + raw_w / cw,

@@ -46,7 +46,9 @@ def main():
     for _ in range(3):
         assert lib.calib_write(z.data_ptr(), nb.data_ptr(), na, st) == 0
     torch.cuda.synchronize()
-    env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1)
+    layer = not os.environ.get("PLAIN")            # the graded path: per-step statistic + in-kernel auto-reset
+    env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1,
+                 auto_reset=layer, track_episodes=layer)
     g = torch.Generator(device="cuda").manual_seed(0)
     pool = torch.rand(n, E, N, 2, device="cuda", generator=g) * 2 - 1
     for s in range(n):

@@ -1,20 +1,27 @@
 #!/bin/bash
 # Re-measure everything profiles/ holds, on the MI355X box:
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r1'
+#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r2'
 # writes gpurun_out/<tag>_*; copy the summaries into profiles/ afterwards (see profiles/README.md).
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py --steps 2000 --warmup 200 > $OUT/${TAG}_c3_bench.json 2> $OUT/${TAG}_c3_bench.err
-tail -1 $OUT/${TAG}_c3_bench.json
+T="timeout 280"
+$T python bench.py --steps 2000 --warmup 200 > $OUT/${TAG}_c3_bench.json 2> $OUT/${TAG}_c3_bench.err
+tail -1 $OUT/${TAG}_c3_bench.json | cut -c1-400
+$T python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_c3_bench_steps20.json 2>> $OUT/${TAG}_c3_bench.err
+$T python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-episode-layer > $OUT/${TAG}_c3_bench_plain.json 2>> $OUT/${TAG}_c3_bench.err
+$T python bench.py --workload c5 --steps 1000 --warmup 100 --no-cpu-baseline > $OUT/${TAG}_c5_bench.json 2>> $OUT/${TAG}_c3_bench.err
+$T python bench.py --workload c5 --policy gaussian --steps 400 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_c5_gaussian_f32_bench.json 2>> $OUT/${TAG}_c3_bench.err
+$T python bench.py --workload c5 --policy gaussian --policy-precision bf16 --steps 400 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_c5_gaussian_bf16_bench.json 2>> $OUT/${TAG}_c3_bench.err
+$T python bench.py --workload c2 --steps 2000 --warmup 200 --no-cpu-baseline > $OUT/${TAG}_c2_bench.json 2>> $OUT/${TAG}_c3_bench.err
 cd /tmp
 prof() {   # name, command...
     local name=$1; shift
     rm -rf $OUT/prof_$name
-    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -- "$@" > $OUT/prof_$name.log 2>&1
+    $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -- "$@" > $OUT/prof_$name.log 2>&1
     cp $(find $OUT/prof_$name -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_${name}_kernel_stats.csv
 }
 (cd $ROOT && prof c3_bench python bench.py --steps 1000 --warmup 100 --no-cpu-baseline)
@@ -22,12 +29,16 @@ cp $(find $OUT/prof_c3_bench -name '*domain_stats.csv' | head -1) $OUT/${TAG}_c3
 (cd $ROOT && prof c3_kbench python tools/kbench.py c3)
 (cd $ROOT && prof rollout python tools/rbench.py c3 c5)
 (cd $ROOT && prof c3_policy python tools/pbench.py c3)
+(cd $ROOT && prof c5_policy python tools/pbench.py c5)
+(cd $ROOT && prof fbench python tools/fbench.py)
+(cd $ROOT && prof reset_probe python tools/reset_probe.py c3)
 for c in FETCH_SIZE WRITE_SIZE; do
     d=$OUT/pmc_$TAG/$( [ $c = FETCH_SIZE ] && echo fetch || echo write )
     rm -rf $d
-    (cd $ROOT && rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python tools/pmc_run.py c3 > $OUT/pmc_${TAG}_$c.log 2>&1)
+    (cd $ROOT && $T rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python tools/pmc_run.py c3 > $OUT/pmc_${TAG}_$c.log 2>&1)
 done
 (cd $ROOT/tools && python pmc_parse.py $OUT/pmc_$TAG c3 > $OUT/${TAG}_c3_pmc_traffic.json)
 tail -5 $OUT/${TAG}_c3_pmc_traffic.json
-(cd $ROOT && python tools/kbench.py c3 c2 c5 256x4096:256:2.5 c3x8 > $OUT/${TAG}_kbench.log 2>&1; python tools/pbench.py c3 c5 > $OUT/${TAG}_pbench.log 2>&1; python tools/rbench.py c3 c5 > $OUT/${TAG}_rbench.log 2>&1)
+(cd $ROOT && bash tools/sq_counters.sh $TAG c3 > $OUT/${TAG}_sq.log 2>&1)
+(cd $ROOT && $T python tools/kbench.py c3 c2 c5 256x4096:256:2.5 c3x8 > $OUT/${TAG}_kbench.log 2>&1; $T python tools/pbench.py c3 c5 > $OUT/${TAG}_pbench.log 2>&1; $T python tools/rbench.py c3 c5 > $OUT/${TAG}_rbench.log 2>&1; $T python tools/epibench.py 5 c3 > $OUT/${TAG}_epibench.log 2>&1; $T python tools/reset_probe.py c3 c5 c2 > $OUT/${TAG}_reset_probe.log 2>&1; $T python tools/fbench.py > $OUT/${TAG}_fbench.log 2>&1)
 cat $OUT/${TAG}_kbench.log
