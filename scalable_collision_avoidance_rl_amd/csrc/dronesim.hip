@@ -247,7 +247,7 @@ __device__ __forceinline__ float dpp_or_zero(float v)   // v of the lane CTRL se
 // (Tried on the matrix pipe instead -- two chained v_mfma_f32_16x16x4_f32 with B = ones per sum: +0.3 us per launch.)
 __device__ __forceinline__ float2 wave_sum64_pair(float a, float b)
 {
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     const float v = a + b;
     float t = v + dpp_or_zero<0x111, 0xf, 0xf>(v);
     t += dpp_or_zero<0x112, 0xf, 0xf>(v);
@@ -802,6 +802,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         }
         // @phase epilogue_rewards_z
         float r_out = 0.0f, tr_out = 0.0f;                    // this lane's rewards (episode bookkeeping)
+        float r_env = 0.0f, tr_env = 0.0f;                    // their sums over the env, valid in its agent-0 lane
         if (valid) {
             TRACE_MARK(3);
             // rewards (:276, :287-288)
@@ -812,6 +813,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             tr_out = -nan_to_num_f32(fmaf(a.b, s_all, to_goal));
             if (a.reward) st_out(a.reward + so + wga0 + lane, r_out);
             if (a.true_reward) st_out(a.true_reward + so + wga0 + lane, tr_out);
+            if (SYM && has_acc) {                             // all 64 lanes are here (one env per wave): start the
+                const float2 sm = wave_sum64_pair(r_out, tr_out);   // dependent chain now, the rows below overlap it
+                r_env = sm.x; tr_env = sm.y;
+            }
 
             // localized state rows + neighbour list (:344-397)
             const float zx = xi - xFx, zy = yi - xFy;                         // :357
@@ -877,7 +882,6 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         // episode bookkeeping: sum of this step's rewards per env, fixed order (bit-reproducible).  Workgroup-per-env
         // geometries leave one partial per wave in LDS ahead of the barrier below; wave-local geometries reduce after
         // their output stores have been issued (the reduction is a dependent chain: nothing should queue behind it)
-        float r_env = 0.0f, tr_env = 0.0f;                    // valid in the env's agent-0 lane
         if (!WL && has_acc) {
             const float2 sm = wave_sum64_pair(r_out, tr_out);
             if (lane == 0) { spart[2 * wave] = sm.x; spart[2 * wave + 1] = sm.y; }
@@ -902,13 +906,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         TRACE_MARK(4);
         group_sync<WL>();
 #if !defined(DRONESIM_ABL_NOSUM)
-        if (WL && has_acc) {
-            if (SYM) {
-                const float2 sm = wave_sum64_pair(r_out, tr_out);
-                r_env = sm.x; tr_env = sm.y;
-            } else {
-                r_env = segment_sum(r_out, agent, N); tr_env = segment_sum(tr_out, agent, N);
-            }
+        if (WL && !SYM && has_acc) {
+            r_env = segment_sum(r_out, agent, N); tr_env = segment_sum(tr_out, agent, N);
         }
 #endif
 #if defined(DRONESIM_ABLATE_ZOUT)

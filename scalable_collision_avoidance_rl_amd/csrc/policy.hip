@@ -24,6 +24,8 @@
 // LDS row strides are odd (h1+1, 33) so the 32-row fragment reads are bank-conflict free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <mutex>
 
 #include "common.hpp"
 #include "dronesim.h"
@@ -591,15 +593,32 @@ __global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const 
     }
 }
 
+// > 64 KiB of dynamic LDS must be opted into once per (kernel, device): a bit mask of device ordinals per kernel,
+// guarded by a mutex (the library may be driven from several host threads / devices of one process)
+int enable_big_lds(const void *kernel, unsigned long long (&opted)[4], std::mutex &mu, const char *what)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 255) dev = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    if (opted[dev >> 6] >> (dev & 63) & 1ull) return DRONESIM_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "cannot enable 160 KiB of dynamic LDS for %s: %s", what, hipGetErrorString(e));
+        return dronesim_fail(DRONESIM_ELAUNCH, msg);
+    }
+    opted[dev >> 6] |= 1ull << (dev & 63);
+    return DRONESIM_OK;
+}
+
 template <int NC1>
 int launch_bf16(const MArgsB &a, size_t lds, hipStream_t stream)
 {
-    static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
-    if (lds > 48 * 1024 && !big_lds_enabled) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_bf16_kernel<NC1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-            return dronesim_fail(DRONESIM_ELAUNCH, "cannot enable 160 KiB of dynamic LDS for mlp3_bf16_kernel");
-        big_lds_enabled = true;
+    if (lds > 48 * 1024) {
+        static std::mutex mu;
+        static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
+        const int rc = enable_big_lds(reinterpret_cast<const void *>(mlp3_bf16_kernel<NC1>), opted, mu, "mlp3_bf16_kernel");
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(mlp3_bf16_kernel<NC1>, dim3(((a.E + kRowsB - 1) / kRowsB) * a.N), dim3(256), lds, stream,
                        a.x, a.E, a.N, a.d_in, a);
@@ -698,14 +717,13 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
     const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + (kThreadsF / 64) * 32 * 33);
-    static bool big_lds_enabled = false;                 // > 64 KiB of dynamic LDS must be opted into once
-    if (!big_lds_enabled) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(mlp3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024) != hipSuccess)
-            return dronesim_fail(DRONESIM_ELAUNCH, "cannot enable 160 KiB of dynamic LDS for mlp3_kernel");
-        big_lds_enabled = true;
-    }
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
+    {
+        static std::mutex mu;
+        static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
+        const int lrc = enable_big_lds(reinterpret_cast<const void *>(mlp3_kernel), opted, mu, "mlp3_kernel");
+        if (lrc) return lrc;
+    }
     hipLaunchKernelGGL(mlp3_kernel, dim3(((E + kRows - 1) / kRows) * m->N), dim3(kThreadsF), lds, static_cast<hipStream_t>(stream),
                        a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();
