@@ -98,6 +98,10 @@ def lib():
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
             "scalable_collision_avoidance_rl_amd/csrc`) with hipcc for gfx950. "
             "There is no CPU fallback for this path.")
+    # torch first: the library's HIP calls must bind to the HIP runtime torch ships and initialises (the buffers and
+    # streams handed across the ABI live there); loaded on its own, the library would pull in the system's copy and
+    # see no context ("no ROCm-capable device is detected" at the first launch)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, u64, i64, f32 = C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_float
     P = C.POINTER(DroneParams)
