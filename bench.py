@@ -292,6 +292,20 @@ def main():
         ro_us = float(np.median(rs))
     except RuntimeError:                               # e.g. not enough memory for the [T, ...] outputs
         ro_us = None
+    # and with the actions drawn inside the kernel (dronesim_rollout_random: RandomAgent.forward, SAC_agents.py:22,
+    # from a counter-based stream; no action pool, 44 B/agent-step), episode layer on: runs across episode ends
+    rr_us = None
+    try:
+        env.reset(renew_obstacles=False)
+        out = env.rollout_random(T_ep); torch.cuda.synchronize(); del out
+        rs = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); out = env.rollout_random(T_ep); e1.record(); torch.cuda.synchronize(); del out
+            rs.append(e0.elapsed_time(e1) * 1e3 / T_ep)
+        rr_us = float(np.median(rs))
+    except RuntimeError:
+        rr_us = None
 
     el = torch.tensor([elapsed, eager_elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -327,7 +341,11 @@ def main():
                       "note": "the same K steps launched one by one from Python (host launch latency included)"},
             "fused_rollout": None if ro_us is None else {
                 "us_per_step_per_gpu": ro_us, "agent_steps_per_s_per_gpu": N * E / ro_us * 1e6,
-                "note": "dronesim_rollout: 200 steps per launch, 52 B/agent-step (no per-step state write-back)"},
+                "note": "dronesim_rollout: 200 steps per launch, 52 B/agent-step (no per-step state write-back)",
+                "random_actions_in_kernel": None if rr_us is None else {
+                    "us_per_step_per_gpu": rr_us, "agent_steps_per_s_per_gpu": N * E / rr_us * 1e6,
+                    "note": "dronesim_rollout_random: actions drawn in the kernel (no action pool, 44 B/agent-step), "
+                            "episode records + in-kernel reset on"}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, G, delta, args.cpu_budget)

@@ -26,3 +26,17 @@ for spec in (sys.argv[1:] or ["c3"]):
         us = min(ts)
         byt = 52 * N * E
         print(f"{spec} rollout T={T:4d}: {us:7.2f} us/step  {N*E/us*1e6:.3e} agent-steps/s  {byt/us/1e3:7.1f} GB/s (52 B/agent-step)", flush=True)
+    # the same T = 200 steps with the actions drawn in the kernel (dronesim_rollout_random: 44 B/agent-step, no pool),
+    # plain and with the episode layer (records + in-kernel reset: the rollout runs across episode ends)
+    for label, kw in (("random actions", {}), ("random + records + auto-reset", dict(auto_reset=True))):
+        T = 200
+        env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1, **kw)
+        out = env.rollout_random(T); torch.cuda.synchronize(); del out
+        ts = []
+        for _ in range(5):
+            env.reset(renew_obstacles=False)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); out = env.rollout_random(T); b.record(); torch.cuda.synchronize(); del out
+            ts.append(a.elapsed_time(b) * 1e3 / T)
+        us = min(ts)
+        print(f"{spec} rollout T={T:4d}, {label}: {us:7.2f} us/step  {N*E/us*1e6:.3e} agent-steps/s  {44*N*E/us/1e3:7.1f} GB/s (44 B/agent-step)", flush=True)
