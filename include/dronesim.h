@@ -303,6 +303,17 @@ int dronesim_observe_f64(const DroneParamsF64 *p, const double *pos, const doubl
                          double *reward, double *true_reward, double *z, int32_t *nbr_idx,
                          int32_t *n_coll, int E, void *stream);
 
+/* float32-ACCURATE variant on the bf16 matrix instructions ("bf16x3"): every weight and activation is split by
+ * truncation into three bf16 parts, v = hi + mid + lo exactly, and a product is the float32 sum of its six largest
+ * partial products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the rest is below 2^-24 of the product).  Results
+ * agree with dronesim_mlp_forward to float32 round-off (same 1e-5 bar against the reference's modules) at 6/16 of
+ * its matrix time.  Same struct as the bf16 variant, but every packed array holds THREE fragments per
+ * (agent, chunk, k-step) -- the hi, mid and lo parts, [agent][chunk][k-step][part][64 lanes][8] bf16 -- and layers 2
+ * AND 3 use the "accumulator" k order (kmap(s, h, j) = 16 s + 8 (j >> 2) + 4 h + (j & 3)), layer 1 the linear one.  */
+int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                                uint64_t seed, uint64_t counter, int64_t env_base,
+                                const int32_t *t, const int32_t *episode, int E, void *stream);
+
 const char *dronesim_last_error(void);
 const char *dronesim_error_string(int code);
 int dronesim_version(void);

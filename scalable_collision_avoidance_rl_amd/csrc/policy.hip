@@ -593,6 +593,239 @@ __global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3 variant: float32-ACCURATE results on the bf16 matrix instructions.  Every float32 operand is split by
+// truncation into three bf16 parts, x = hi + mid + lo EXACTLY (8 + 8 + 8 significant bits), and a product is the sum
+// of the six partial products of weight at least 2^-16:  hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid  (the dropped
+// ones are below 2^-24 of the product), accumulated in float32, smallest first.  Six v_mfma_f32_32x32x16_bf16 per
+// k-step of 16 cost 6/16 of the matrix time of the eight v_mfma_f32_32x32x2_f32 they replace; the result meets the
+// reference's own torch modules to the 1e-5 bar like the exact-f32 kernel (tools/split_bf16_emulation.py: a two-part
+// split with three products does NOT -- 4-5x over the bar on the Gaussian and critic heads).
+// Weights are split and packed per fragment on the host (policies.py), [agent][chunk][k-step][part][64 lanes] x 16 B.
+// The three layers are fused in REGISTERS, transposed like the bf16 kernel (D[feature][env row]): one workgroup =
+// 32 env rows of one agent, 4 waves; wave w owns the output chunks w, w+4, ... of layer 2 and keeps their
+// accumulators for the whole launch while it streams over the first hidden layer chunk by chunk -- each chunk of h1 is
+// computed where it is consumed (layer 1 has K = d_in <= 16: one k-step), bias + relu + split happen on the
+// accumulator registers, whose layout IS a valid B operand once the k order of W2 / W3 is permuted to match on the
+// host ("accumulator" order, include/dronesim.h).  No activation ever touches LDS; the only barrier is the final
+// sum of the four waves' layer-3 partials.  Non-finite activations are outside the split's domain (inf - inf).
+constexpr int kTilesX = 2;                 // row tiles per wave: every weight fragment loaded feeds 12 matrix instructions
+constexpr int kRowsX = 32 * kTilesX;       // env rows per workgroup
+
+struct MArgsX {
+    int E, N, d_in, h1, h2, nc1, nc2;
+    const float *x, *b1, *b2, *b3;
+    const bf16x8 *w1x, *w2x, *w3x;
+    FinishArgs fin;
+};
+
+struct Split3 { bf16x8 hi, mid, lo; };
+
+// eight float32 values -> their three bf16 parts (truncation: the upper 16 bits of a float32 ARE a bf16)
+__device__ __forceinline__ Split3 split3(const float (&v)[8])
+{
+    unsigned h[8], m[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned b = __float_as_uint(v[j]);
+        h[j] = b;
+        const float rem = v[j] - __uint_as_float(b & 0xffff0000u);
+        const unsigned rb = __float_as_uint(rem);
+        m[j] = rb;
+        l[j] = __float_as_uint(rem - __uint_as_float(rb & 0xffff0000u));
+    }
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    u32x4v ph, pm, pl;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                      // upper halves of two dwords -> one dword (element 2q low)
+        ph[q] = __builtin_amdgcn_perm(h[2 * q + 1], h[2 * q], 0x07060302u);
+        pm[q] = __builtin_amdgcn_perm(m[2 * q + 1], m[2 * q], 0x07060302u);
+        pl[q] = __builtin_amdgcn_perm(l[2 * q + 1], l[2 * q], 0x07060302u);
+    }
+    Split3 r;
+    r.hi = __builtin_bit_cast(bf16x8, ph); r.mid = __builtin_bit_cast(bf16x8, pm); r.lo = __builtin_bit_cast(bf16x8, pl);
+    return r;
+}
+
+// acc[t] += W * B[t] for every row tile, both operands in three parts: the six products, smallest first; the tiles
+// alternate so that consecutive matrix instructions never wait on each other's accumulator
+__device__ __forceinline__ void mfma6(f32x16 (&acc)[kTilesX], const bf16x8 (&w)[3], const Split3 (&b)[kTilesX])
+{
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], b[t].hi, acc[t], 0, 0, 0);    // lo * hi
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[t].lo, acc[t], 0, 0, 0);    // hi * lo
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], b[t].mid, acc[t], 0, 0, 0);   // mid * mid
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], b[t].hi, acc[t], 0, 0, 0);    // mid * hi
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[t].mid, acc[t], 0, 0, 0);   // hi * mid
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[t].hi, acc[t], 0, 0, 0);    // hi * hi
+}
+
+// relu(acc + bias) of a finished 32-feature chunk -> k-step `s` (0 / 1) of the next layer's B operand, three parts.
+// `bias` points at the chunk's 32 biases in LDS; registers 8 s .. 8 s + 7 of a lane are the k slots of k-step s.
+__device__ __forceinline__ Split3 chunk_to_operand(const f32x16 &acc, const float *bias, int lane, int s)
+{
+    const float *bc = bias + 4 * (lane >> 5);
+    const float4 b0 = *reinterpret_cast<const float4 *>(bc + 16 * s);
+    const float4 b1 = *reinterpret_cast<const float4 *>(bc + 16 * s + 8);
+    float v[8];
+    v[0] = fmaxf(acc[8 * s + 0] + b0.x, 0.0f); v[1] = fmaxf(acc[8 * s + 1] + b0.y, 0.0f);
+    v[2] = fmaxf(acc[8 * s + 2] + b0.z, 0.0f); v[3] = fmaxf(acc[8 * s + 3] + b0.w, 0.0f);
+    v[4] = fmaxf(acc[8 * s + 4] + b1.x, 0.0f); v[5] = fmaxf(acc[8 * s + 5] + b1.y, 0.0f);
+    v[6] = fmaxf(acc[8 * s + 6] + b1.z, 0.0f); v[7] = fmaxf(acc[8 * s + 7] + b1.w, 0.0f);
+    return split3(v);
+}
+
+__global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int E, int N, int d_in, const MArgsX rest)
+{
+    MArgsX a = rest;
+    a.x = x; a.E = E; a.N = N; a.d_in = d_in;
+    constexpr int kMaxChunks = 4;                        // layer-2 chunks per wave: h2 <= 512
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int agent, row_block;
+    xcd_work_item((a.E + kRowsX - 1) / kRowsX, agent, row_block);
+    const int e0 = row_block * kRowsX;
+    const int NC1 = a.nc1, KS2 = 2 * a.nc1;
+    const int nb = (a.nc1 + a.nc2) * 32;
+    float *sbias = reinterpret_cast<float *>(smem);                // b1 | b2 (zero padded to chunks) | b3 (32)
+    float *spart = sbias + nb + 32;                                // [4 waves][kRowsX rows][33]
+
+    // ---- this lane's slice of the x operand per row tile: row 32 t + (lane & 31), inputs 8 (lane >> 5) .. + 7
+    Split3 xB[kTilesX];
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t) {
+        const int e = e0 + 32 * t + (lane & 31), k0 = 8 * (lane >> 5);
+        const float *xr = a.x + ((size_t)min(e, a.E - 1) * a.N + agent) * a.d_in;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xv = xr[min(k0 + j, a.d_in - 1)];          // clamped address, masked value: no branches
+            v[j] = (e < a.E && k0 + j < a.d_in) ? xv : 0.0f;
+        }
+        xB[t] = split3(v);
+    }
+    uint32_t tval = 0, epval = 0;
+    if (e0 + (tid >> 2) < a.E && a.fin.sample_kind != 0) {          // of the row this thread finishes (4 lanes per row)
+        if (a.fin.t_dev) tval = (uint32_t)a.fin.t_dev[e0 + (tid >> 2)];
+        if (a.fin.episode_dev) epval = (uint32_t)a.fin.episode_dev[e0 + (tid >> 2)];
+    }
+    for (int idx = tid; idx < nb + 32; idx += 256) {               // biases -> LDS, zero padded
+        float v = 0.0f;
+        if (idx < a.nc1 * 32) { if (idx < a.h1) v = a.b1[(size_t)agent * a.h1 + idx]; }
+        else if (idx < nb) { if (idx - a.nc1 * 32 < a.h2) v = a.b2[(size_t)agent * a.h2 + idx - a.nc1 * 32]; }
+        else if (idx - nb < a.fin.nout) v = a.b3[(size_t)agent * a.fin.nout + idx - nb];
+        sbias[idx] = v;
+    }
+    __syncthreads();
+
+    const bf16x8 *w1a = a.w1x + (size_t)agent * NC1 * 3 * 64 + lane;                  // [c1][part][lane]
+    const bf16x8 *w2a = a.w2x + (size_t)agent * a.nc2 * KS2 * 3 * 64 + lane;          // [c2][s][part][lane]
+    const bf16x8 *w3a = a.w3x + (size_t)agent * a.nc2 * 2 * 3 * 64 + lane;            // [s = 2 c2 + ss][part][lane]
+    f32x16 acc2[kMaxChunks][kTilesX];
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i)
+#pragma unroll
+        for (int t = 0; t < kTilesX; ++t) acc2[i][t] = f32x16{};
+
+    // ---- stream over the chunks of the first hidden layer.  Weight fragments run one stage (the three parts of one
+    //      (chunk, k-step)) ahead of the matrix instructions that consume them, across chunk borders.  Measured and
+    //      dropped: two stages ahead (-6 %: registers, not L2 latency, are short at 2 waves per SIMD), and pinning an
+    //      interleaving of the split arithmetic with the matrix instructions by sched_group_barrier (-14 %: the two
+    //      waves of a SIMD already alternate between their vector and matrix phases on their own).
+    bf16x8 w1f[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) w1f[p] = w1a[(size_t)p * 64];
+    const int nmine = (a.nc2 - wave + 3) / 4;                      // output chunks of this wave (wave-uniform)
+    bf16x8 cur[3], nxt[3];
+    auto w2_stage = [&](int c1, int ss, int i, bf16x8 (&dst)[3]) {
+        const bf16x8 *wp = w2a + ((size_t)(wave + 4 * i) * KS2 + 2 * c1 + ss) * 3 * 64;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dst[p] = wp[(size_t)p * 64];
+    };
+    if (nmine > 0) w2_stage(0, 0, 0, cur);
+    for (int c1 = 0; c1 < NC1; ++c1) {
+        f32x16 a1[kTilesX];
+#pragma unroll
+        for (int t = 0; t < kTilesX; ++t) a1[t] = f32x16{};
+        mfma6(a1, w1f, xB);                                        // layer 1, chunk c1 (one k-step of 16 inputs)
+        if (c1 + 1 < NC1) {                                        // next chunk's layer-1 fragments, a whole chunk ahead
+#pragma unroll
+            for (int p = 0; p < 3; ++p) w1f[p] = w1a[((size_t)(c1 + 1) * 3 + p) * 64];
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            Split3 hB[kTilesX];
+#pragma unroll
+            for (int t = 0; t < kTilesX; ++t) hB[t] = chunk_to_operand(a1[t], sbias + c1 * 32, lane, ss);
+#pragma unroll
+            for (int i = 0; i < kMaxChunks; ++i) {
+                if (i < nmine) {                                   // wave-uniform
+                    // request the stage after this one: next chunk of mine, else the next k-step / h1 chunk
+                    int ni = i + 1, nss = ss, nc1 = c1;
+                    if (ni >= nmine) { ni = 0; nss = ss + 1; if (nss == 2) { nss = 0; nc1 = c1 + 1; } }
+                    if (nc1 < NC1) w2_stage(nc1, nss, ni, nxt);
+                    mfma6(acc2[i], cur, hB);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) cur[p] = nxt[p];
+                }
+            }
+        }
+    }
+
+    // ---- layer 3 from the finished layer-2 accumulators
+    f32x16 y[kTilesX];
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t) y[t] = f32x16{};
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c2 = wave + 4 * i;
+        if (c2 < a.nc2) {
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                const bf16x8 *wp = w3a + ((size_t)(2 * c2 + ss)) * 3 * 64;
+                bf16x8 wf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wf[p] = wp[(size_t)p * 64];
+                Split3 pB[kTilesX];
+#pragma unroll
+                for (int t = 0; t < kTilesX; ++t) pB[t] = chunk_to_operand(acc2[i][t], sbias + (a.nc1 + c2) * 32, lane, ss);
+                mfma6(y, wf, pB);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kTilesX; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            spart[((size_t)wave * kRowsX + t * 32 + (lane & 31)) * 33 + cd_row(r, lane)] = y[t][r];
+    __syncthreads();
+
+    {                                                              // activation + sampling: four lanes per env row
+        const int row = tid >> 2, part = tid & 3;
+        const int e = e0 + row;
+        if (e >= a.E) return;
+        float yv[kQ];
+#pragma unroll
+        for (int i = 0; i < kQ; ++i) {
+            const int j = part + 4 * i;
+            float v = 0.0f;
+            if (j < a.fin.nout) {
+                v = sbias[nb + j];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += spart[((size_t)w * kRowsX + row) * 33 + j];
+            }
+            yv[i] = v;
+        }
+        finish_quad(a.fin, yv, e, agent, part, tval, epval);
+    }
+}
+
 // > 64 KiB of dynamic LDS must be opted into once per (kernel, device): a bit mask of device ordinals per kernel,
 // guarded by a mutex (the library may be driven from several host threads / devices of one process)
 int enable_big_lds(const void *kernel, unsigned long long (&opted)[4], std::mutex &mu, const char *what)
@@ -694,6 +927,32 @@ extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, 
         default: return dronesim_fail(DRONESIM_EUNSUPPORTED, "bf16 path: h1 <= 512");
     }
     if (lrc) return lrc;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
+}
+
+extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                                           uint64_t seed, uint64_t counter, int64_t env_base,
+                                           const int32_t *t, const int32_t *episode, int E, void *stream)
+{
+    if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16x3: NULL argument");
+    const int rc = check_mlp("bf16x3", m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
+    if (rc) return rc;
+    if (m->d_in > 16) return dronesim_fail(DRONESIM_EUNSUPPORTED, "bf16x3 path: d_in <= 16");
+    if (!m->w1p || !m->w2p || !m->w3p || !m->b1 || !m->b2 || !m->b3)
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16x3: NULL weight array");
+    if (E == 0) return DRONESIM_OK;
+    MArgsX a{};
+    a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2;
+    a.nc1 = (m->h1 + 31) / 32; a.nc2 = (m->h2 + 31) / 32;
+    a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
+    a.w1x = reinterpret_cast<const bf16x8 *>(m->w1p); a.w2x = reinterpret_cast<const bf16x8 *>(m->w2p);
+    a.w3x = reinterpret_cast<const bf16x8 *>(m->w3p);
+    a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
+    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32 + 4 * kRowsX * 33);
+    hipLaunchKernelGGL(mlp3_bf16x3_kernel, dim3(((E + kRowsX - 1) / kRowsX) * m->N), dim3(256), lds,
+                       static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

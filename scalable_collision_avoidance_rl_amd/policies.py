@@ -48,6 +48,26 @@ def pack_bf16_fragments(w, ksteps, nchunks, k_order="linear"):
     return frag.reshape(n, nchunks, ksteps, 64, 8).to(torch.bfloat16).contiguous()
 
 
+def split3_bf16(w):
+    """float32 tensor -> its three bf16 parts by truncation, ``w == hi + mid + lo`` exactly (each part is a float32
+    tensor whose low 16 bits are zero, i.e. exactly representable in bf16)."""
+    import torch
+    w = w.float().contiguous()
+    hi = (w.view(torch.int32) & -65536).view(torch.float32)
+    rem = w - hi
+    mid = (rem.view(torch.int32) & -65536).view(torch.float32)
+    lo = rem - mid
+    return hi, mid, lo
+
+
+def pack_bf16x3_fragments(w, ksteps, nchunks, k_order):
+    """[N, K, F] float32 weights -> ``[N, nchunks, ksteps, 3, 64, 8]`` bf16: the hi / mid / lo fragments of
+    `dronesim_mlp_forward_bf16x3` side by side per (agent, chunk, k-step)."""
+    import torch
+    parts = [pack_bf16_fragments(p, ksteps, nchunks, k_order) for p in split3_bf16(w)]
+    return torch.stack(parts, dim=3).contiguous()
+
+
 def stack_reference_modules(modules, kind=None):
     """Per-agent modules -> ``(w1, b1, w2, b2, w3, b3, out_kind, sample_kind)`` with a leading agent axis
     (CPU tensors; pure torch, no GPU needed).  ``kind``: 'discrete_softmax' | 'normal_actor' | 'critic',
@@ -81,8 +101,10 @@ def stack_reference_modules(modules, kind=None):
 class BatchedMLP:
     def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0, precision="f32"):
         """w1 [N,d_in,h1], b1 [N,h1], w2 [N,h1,h2], b2 [N,h2], w3 [N,h2,nout], b3 [N,nout] (float32).
-        ``precision="f32"`` (default) is exact float32 on the matrix cores; ``"bf16"`` runs weights and
-        activations in bfloat16 with float32 accumulation (~1e-2 relative agreement, much faster)."""
+        ``precision="f32"`` (default) is exact float32 on the matrix cores; ``"bf16x3"`` gives float32-accurate
+        results (same 1e-5 bar) from three-part bf16 splits of weights and activations on the bf16 matrix
+        instructions, ~2.5x faster; ``"bf16"`` runs weights and activations in plain bfloat16 with float32
+        accumulation (~1e-2 relative agreement, fastest)."""
         import torch
         from . import _native
         self._torch, self._native = torch, _native
@@ -117,8 +139,21 @@ class BatchedMLP:
             mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), self._w2p.data_ptr(), self._w3p.data_ptr()
             mb.b1, mb.b2, mb.b3 = self.b1.data_ptr(), self.b2.data_ptr(), self.b3.data_ptr()
             self._m = mb
+        elif precision == "bf16x3":
+            if self.d_in > 16:
+                raise ValueError("the bf16x3 path supports d_in <= 16")
+            nc1, nc2 = (self.h1 + 31) // 32, (self.h2 + 31) // 32
+            self._w1p = pack_bf16x3_fragments(self.w1, 1, nc1, "linear")
+            self._w2p = pack_bf16x3_fragments(self.w2, 2 * nc1, nc2, "accumulator")
+            self._w3p = pack_bf16x3_fragments(self.w3, 2 * nc2, 1, "accumulator")
+            mb = _native.DroneMlpBf16()
+            mb.N, mb.d_in, mb.h1, mb.h2, mb.nout = self.n_agents, self.d_in, self.h1, self.h2, self.nout
+            mb.out_kind, mb.sample_kind = self.out_kind, self.sample_kind
+            mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), self._w2p.data_ptr(), self._w3p.data_ptr()
+            mb.b1, mb.b2, mb.b3 = self.b1.data_ptr(), self.b2.data_ptr(), self.b3.data_ptr()
+            self._m = mb
         elif precision != "f32":
-            raise ValueError("precision must be 'f32' or 'bf16'")
+            raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16'")
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -160,7 +195,8 @@ class BatchedMLP:
             act = torch.empty(E, self.n_agents, 2, device=self.device)
             if self.sample_kind == SAMPLE_CATEGORICAL:
                 idx = torch.empty(E, self.n_agents, dtype=torch.int32, device=self.device)
-        entry = self._lib.dronesim_mlp_forward_bf16 if self.precision == "bf16" else self._lib.dronesim_mlp_forward
+        entry = {"bf16": self._lib.dronesim_mlp_forward_bf16, "bf16x3": self._lib.dronesim_mlp_forward_bf16x3,
+                 "f32": self._lib.dronesim_mlp_forward}[self.precision]
         with torch.cuda.device(self.device):
             rc = entry(C.byref(m), z.data_ptr(), None if out is None else out.data_ptr(),
                                                 None if act is None else act.data_ptr(),

@@ -45,12 +45,12 @@ if __name__ == "__main__":
     for spec in (sys.argv[1:] or ["c3", "c2", "c5"]):
         N, E, G, delta = PRESETS[spec]
         env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1)
-        for kind, prec in [(k, p) for p in ("f32", "bf16") for k in ("softmax16", "gaussian", "critic")]:
+        for kind, prec in [(k, p) for p in (os.environ.get("PB_PREC", "f32,bf16x3,bf16").split(",")) for k in ("softmax16", "gaussian", "critic")]:
             pol, (h1, h2, nout) = rnd_policy(kind, N, 6, env.device, prec)
             z = env.z
             flops = 2.0 * E * N * (6 * h1 + h1 * h2 + h2 * nout)
             us = timeit((lambda: pol.sample_action(z)) if pol.sample_kind else (lambda: pol.forward(z)))
-            line = f"{spec} {kind:>9} {prec:>4}: policy {us:8.1f} us/step = {flops/us/1e6:6.1f} TFLOP/s"
+            line = f"{spec} {kind:>9} {prec:>6}: policy {us:8.1f} us/step = {flops/us/1e6:6.1f} TFLOP/s"
             if pol.sample_kind:
                 def loop():
                     act, _ = pol.sample_action(env.z, env=env)
