@@ -611,6 +611,7 @@ __global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const 
 // sum of the four waves' layer-3 partials.  Non-finite activations are outside the split's domain (inf - inf).
 constexpr int kTilesX = 2;                 // row tiles per wave: every weight fragment loaded feeds 12 matrix instructions
 constexpr int kRowsX = 32 * kTilesX;       // env rows per workgroup
+constexpr int kRingX = 4;                  // stages of the per-wave weight ring in LDS (3 KiB each)
 
 struct MArgsX {
     int E, N, d_in, h1, h2, nc1, nc2;
@@ -665,19 +666,28 @@ __device__ __forceinline__ void mfma6(f32x16 (&acc)[kTilesX], const bf16x8 (&w)[
     for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[t].hi, acc[t], 0, 0, 0);    // hi * hi
 }
 
-// relu(acc + bias) of a finished 32-feature chunk -> k-step `s` (0 / 1) of the next layer's B operand, three parts.
-// `bias` points at the chunk's 32 biases in LDS; registers 8 s .. 8 s + 7 of a lane are the k slots of k-step s.
-__device__ __forceinline__ Split3 chunk_to_operand(const f32x16 &acc, const float *bias, int lane, int s)
+// relu of a finished 32-feature chunk (its bias went in as the accumulator's initial value) -> k-step `s` (0 / 1) of
+// the next layer's B operand, three parts: registers 8 s .. 8 s + 7 of a lane are the k slots of k-step s.
+__device__ __forceinline__ Split3 chunk_to_operand(const f32x16 &acc, int s)
 {
-    const float *bc = bias + 4 * (lane >> 5);
-    const float4 b0 = *reinterpret_cast<const float4 *>(bc + 16 * s);
-    const float4 b1 = *reinterpret_cast<const float4 *>(bc + 16 * s + 8);
     float v[8];
-    v[0] = fmaxf(acc[8 * s + 0] + b0.x, 0.0f); v[1] = fmaxf(acc[8 * s + 1] + b0.y, 0.0f);
-    v[2] = fmaxf(acc[8 * s + 2] + b0.z, 0.0f); v[3] = fmaxf(acc[8 * s + 3] + b0.w, 0.0f);
-    v[4] = fmaxf(acc[8 * s + 4] + b1.x, 0.0f); v[5] = fmaxf(acc[8 * s + 5] + b1.y, 0.0f);
-    v[6] = fmaxf(acc[8 * s + 6] + b1.z, 0.0f); v[7] = fmaxf(acc[8 * s + 7] + b1.w, 0.0f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[8 * s + j], 0.0f);
     return split3(v);
+}
+
+// The 32 biases of a chunk in accumulator layout (register 4 q + j of a lane = feature 8 q + 4 (lane >> 5) + j):
+// the initial value of the chunk's accumulators.  `bias` = the chunk's 32 floats in LDS.  The reads are inline asm ON
+// PURPOSE: hipcc orders every LDS read it can see behind ALL pending global_load_lds of the wave (s_waitcnt
+// vmcnt(0)), which would drain the weight ring twice per chunk; these bytes were written before the first DMA.
+__device__ __forceinline__ f32x16 bias_tile(const float *bias, int lane)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(bias + 4 * (lane >> 5));
+    float4 q0, q1, q2, q3;
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
+                 "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr) : "memory");
+    return f32x16{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 }
 
 __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int E, int N, int d_in, const MArgsX rest)
@@ -729,50 +739,80 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
     const bf16x8 *w3a = a.w3x + (size_t)agent * a.nc2 * 2 * 3 * 64 + lane;            // [s = 2 c2 + ss][part][lane]
     f32x16 acc2[kMaxChunks][kTilesX];
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i)
+    for (int i = 0; i < kMaxChunks; ++i) {                         // start from the layer-2 biases (zero padded)
+        const f32x16 b = bias_tile(sbias + (a.nc1 + min(wave + 4 * i, a.nc2 - 1)) * 32, lane);
 #pragma unroll
-        for (int t = 0; t < kTilesX; ++t) acc2[i][t] = f32x16{};
+        for (int t = 0; t < kTilesX; ++t) acc2[i][t] = b;
+    }
 
-    // ---- stream over the chunks of the first hidden layer.  Weight fragments run one stage (the three parts of one
-    //      (chunk, k-step)) ahead of the matrix instructions that consume them, across chunk borders.  Measured and
-    //      dropped: two stages ahead (-6 %: registers, not L2 latency, are short at 2 waves per SIMD), and pinning an
-    //      interleaving of the split arithmetic with the matrix instructions by sched_group_barrier (-14 %: the two
-    //      waves of a SIMD already alternate between their vector and matrix phases on their own).
-    bf16x8 w1f[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) w1f[p] = w1a[(size_t)p * 64];
+    // ---- stream over the chunks of the first hidden layer.  The weight fragments of this wave form ONE linear stream
+    //      of 3 KiB stages (the three parts of one (chunk, k-step)):  W1(c1), then W2(c1, ss, i) for ss < 2, i < nmine,
+    //      for every c1.  They travel global -> LDS by the DMA path (global_load_lds, 1 KiB per instruction) into a
+    //      ring PRIVATE to the wave, kRingX - 1 stages ahead of the matrix instructions, and are picked up by three
+    //      ds_read_b128 right before use: the look-ahead costs LDS instead of registers.  The ring needs no barrier
+    //      (one wave writes and reads it); what orders a read behind its DMA is the counted s_waitcnt vmcnt below.
     const int nmine = (a.nc2 - wave + 3) / 4;                      // output chunks of this wave (wave-uniform)
-    bf16x8 cur[3], nxt[3];
-    auto w2_stage = [&](int c1, int ss, int i, bf16x8 (&dst)[3]) {
-        const bf16x8 *wp = w2a + ((size_t)(wave + 4 * i) * KS2 + 2 * c1 + ss) * 3 * 64;
+    char *ring = reinterpret_cast<char *>(spart) + (size_t)wave * kRingX * 3072;
+    int pc1 = 0, pss = 0, pi = -1, pslot = 0;                      // producer cursor: next stage to request (pi < 0: W1)
+    auto request = [&]() {
+        const bf16x8 *gp = pc1 >= NC1 ? w1a                        // past the end: a harmless re-read keeps the count
+                         : pi < 0 ? w1a + (size_t)pc1 * 3 * 64
+                                  : w2a + ((size_t)(wave + 4 * pi) * KS2 + 2 * pc1 + pss) * 3 * 64;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p] = wp[(size_t)p * 64];
+        for (int p = 0; p < 3; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)p * 64),
+                                             (__attribute__((address_space(3))) void *)(ring + pslot * 3072 + p * 1024),
+                                             16, 0, 0);
+        pslot = pslot + 1 == kRingX ? 0 : pslot + 1;
+        if (++pi >= nmine) { pi = 0; if (++pss == 2) { pss = 0; pi = -1; ++pc1; } }
     };
-    if (nmine > 0) w2_stage(0, 0, 0, cur);
-    for (int c1 = 0; c1 < NC1; ++c1) {
-        f32x16 a1[kTilesX];
+    int cslot = 0;
+    auto take = [&](bf16x8 (&dst)[3]) {                            // the oldest requested stage -> registers
+#ifdef DRONESIM_ABL_X3_NOLOAD
 #pragma unroll
-        for (int t = 0; t < kTilesX; ++t) a1[t] = f32x16{};
-        mfma6(a1, w1f, xB);                                        // layer 1, chunk c1 (one k-step of 16 inputs)
-        if (c1 + 1 < NC1) {                                        // next chunk's layer-1 fragments, a whole chunk ahead
+        for (int p = 0; p < 3; ++p) dst[p] = xB[0].hi + (short)cslot;
+#else
+#ifndef DRONESIM_ABL_X3_NODMA
+        request();                                                 // into the slot the previous take() emptied
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (kRingX - 1)) : "memory");
+#endif
+#ifdef DRONESIM_ABL_X3_NOREAD
 #pragma unroll
-            for (int p = 0; p < 3; ++p) w1f[p] = w1a[((size_t)(c1 + 1) * 3 + p) * 64];
-        }
+        for (int p = 0; p < 3; ++p) dst[p] = xB[0].hi + (short)cslot;
+#else
+        const char *sp = ring + cslot * 3072 + lane * 16;
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-            Split3 hB[kTilesX];
+        for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<const bf16x8 *>(sp + p * 1024);
+#endif
+#endif
+        cslot = cslot + 1 == kRingX ? 0 : cslot + 1;
+    };
+    if (nmine > 0) {
+#pragma unroll 1
+        for (int j = 0; j < kRingX - 1; ++j) request();
+        for (int c1 = 0; c1 < NC1; ++c1) {
+            f32x16 a1[kTilesX];
+            a1[0] = bias_tile(sbias + c1 * 32, lane);
 #pragma unroll
-            for (int t = 0; t < kTilesX; ++t) hB[t] = chunk_to_operand(a1[t], sbias + c1 * 32, lane, ss);
+            for (int t = 1; t < kTilesX; ++t) a1[t] = a1[0];
+            bf16x8 wf[3];
+            take(wf);
+            mfma6(a1, wf, xB);                                     // layer 1, chunk c1 (one k-step of 16 inputs)
 #pragma unroll
-            for (int i = 0; i < kMaxChunks; ++i) {
-                if (i < nmine) {                                   // wave-uniform
-                    // request the stage after this one: next chunk of mine, else the next k-step / h1 chunk
-                    int ni = i + 1, nss = ss, nc1 = c1;
-                    if (ni >= nmine) { ni = 0; nss = ss + 1; if (nss == 2) { nss = 0; nc1 = c1 + 1; } }
-                    if (nc1 < NC1) w2_stage(nc1, nss, ni, nxt);
-                    mfma6(acc2[i], cur, hB);
+            for (int ss = 0; ss < 2; ++ss) {
+                Split3 hB[kTilesX];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) cur[p] = nxt[p];
+#ifdef DRONESIM_ABL_X3_NOSPLIT
+                for (int t = 0; t < kTilesX; ++t) { hB[t] = xB[t]; hB[t].hi[0] += (short)a1[t][8 * ss]; }
+#else
+                for (int t = 0; t < kTilesX; ++t) hB[t] = chunk_to_operand(a1[t], ss);
+#endif
+#pragma unroll
+                for (int i = 0; i < kMaxChunks; ++i) {
+                    if (i < nmine) {                               // wave-uniform
+                        take(wf);
+                        mfma6(acc2[i], wf, hB);
+                    }
                 }
             }
         }
@@ -794,11 +834,13 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
                 for (int p = 0; p < 3; ++p) wf[p] = wp[(size_t)p * 64];
                 Split3 pB[kTilesX];
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) pB[t] = chunk_to_operand(acc2[i][t], sbias + (a.nc1 + c2) * 32, lane, ss);
+                for (int t = 0; t < kTilesX; ++t) pB[t] = chunk_to_operand(acc2[i][t], ss);
                 mfma6(y, wf, pB);
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the partial sums reuse the rings: no DMA may land late
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < kTilesX; ++t)
 #pragma unroll
@@ -950,7 +992,8 @@ extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x
     a.w1x = reinterpret_cast<const bf16x8 *>(m->w1p); a.w2x = reinterpret_cast<const bf16x8 *>(m->w2p);
     a.w3x = reinterpret_cast<const bf16x8 *>(m->w3p);
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
-    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32 + 4 * kRowsX * 33);
+    const size_t part_bytes = sizeof(float) * 4 * kRowsX * 33, ring_bytes = (size_t)4 * kRingX * 3072;   // the two share LDS
+    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32) + (part_bytes > ring_bytes ? part_bytes : ring_bytes);
     hipLaunchKernelGGL(mlp3_bf16x3_kernel, dim3(((E + kRowsX - 1) / kRowsX) * m->N), dim3(256), lds,
                        static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();
