@@ -307,9 +307,15 @@ int dronesim_observe_f64(const DroneParamsF64 *p, const double *pos, const doubl
  * truncation into three bf16 parts, v = hi + mid + lo exactly, and a product is the float32 sum of its six largest
  * partial products (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid; the rest is below 2^-24 of the product).  Results
  * agree with dronesim_mlp_forward to float32 round-off (same 1e-5 bar against the reference's modules) at 6/16 of
- * its matrix time.  Same struct as the bf16 variant, but every packed array holds THREE fragments per
- * (agent, chunk, k-step) -- the hi, mid and lo parts, [agent][chunk][k-step][part][64 lanes][8] bf16 -- and layers 2
- * AND 3 use the "accumulator" k order (kmap(s, h, j) = 16 s + 8 (j >> 2) + 4 h + (j & 3)), layer 1 the linear one.  */
+ * its matrix time.  Same struct as the bf16 variant with a different weight image: w1p holds, per (agent, wave w < 4),
+ * ONE stream of S = dronesim_mlp_bf16x3_stages(h1, h2) stages of 3 KiB -- a stage = the hi | mid | lo fragments
+ * [3][64 lanes][8] bf16 of one (32-feature chunk, k-step), packed as for the bf16 variant with layers 2 AND 3 in the
+ * "accumulator" k order (kmap(s, h, j) = 16 s + 8 (j >> 2) + 4 h + (j & 3)) and layer 1 in the linear one -- in the
+ * order the kernel consumes them.  With W1(c) = layer 1, chunk c;  W2(c, ss, i) = layer 2, chunk w + 4 i, k-step
+ * 2 c + ss;  W3(i, ss) = layer 3, k-step 2 (w + 4 i) + ss;  i running over the wave's chunks (w + 4 i < ceil(h2/32)):
+ *     W1(0), W2(0,0,*), W1(1), W2(0,1,*), W2(1,0,*), W1(2), W2(1,1,*), ..., W2(C-1,1,*), W3(0,0), W3(0,1), W3(1,0), ...
+ * then zero stages up to S.  [N][4][S][3][64][8] bf16 in all; w2p / w3p are unused, `reserved` must hold S.  */
+int dronesim_mlp_bf16x3_stages(int h1, int h2);
 int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                                 uint64_t seed, uint64_t counter, int64_t env_base,
                                 const int32_t *t, const int32_t *episode, int E, void *stream);

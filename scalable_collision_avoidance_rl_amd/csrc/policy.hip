@@ -612,83 +612,103 @@ __global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const 
 constexpr int kTilesX = 2;                 // row tiles per wave: every weight fragment loaded feeds 12 matrix instructions
 constexpr int kRowsX = 32 * kTilesX;       // env rows per workgroup
 constexpr int kRingX = 4;                  // stages of the per-wave weight ring in LDS (3 KiB each)
+constexpr int kXbBytes = kTilesX * 3 * 64 * 16;   // the split x operand of the workgroup in LDS
 
 struct MArgsX {
     int E, N, d_in, h1, h2, nc1, nc2;
     const float *x, *b1, *b2, *b3;
-    const bf16x8 *w1x, *w2x, *w3x;
+    const bf16x8 *ws;              // the per-(agent, wave) fragment streams
+    int stages;                    // stages per stream (padded)
     FinishArgs fin;
 };
 
-struct Split3 { bf16x8 hi, mid, lo; };
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Parts3 { u32x4 hi, mid, lo; };      // the three bf16 parts of a lane's 8 k-slots (two per dword, low half first)
 
-// eight float32 values -> their three bf16 parts (truncation: the upper 16 bits of a float32 ARE a bf16)
-__device__ __forceinline__ Split3 split3(const float (&v)[8])
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
+
+// One float32 -> the bit patterns whose upper halves are its three bf16 parts (truncation: the upper 16 bits of a
+// float32 ARE a bf16; v = hi + mid + lo exactly).  5 vector instructions with the relu.
+__device__ __forceinline__ void split_value(float v, unsigned &h, unsigned &m, unsigned &l)
 {
-    unsigned h[8], m[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const unsigned b = __float_as_uint(v[j]);
-        h[j] = b;
-        const float rem = v[j] - __uint_as_float(b & 0xffff0000u);
-        const unsigned rb = __float_as_uint(rem);
-        m[j] = rb;
-        l[j] = __float_as_uint(rem - __uint_as_float(rb & 0xffff0000u));
+    v = fmaxf(v, 0.0f);
+    h = __float_as_uint(v);
+    const float rem = v - __uint_as_float(h & 0xffff0000u);
+    m = __float_as_uint(rem);
+    l = __float_as_uint(rem - __uint_as_float(m & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned upper_halves(unsigned odd, unsigned even)      // -> {even.hi16 (low), odd.hi16 (high)}
+{
+    return __builtin_amdgcn_perm(odd, even, 0x07060302u);
+}
+
+// relu + split of half an accumulator tile (registers 8 HALF .. 8 HALF + 7 = the k slots of k-step HALF of the next
+// layer's B operand), one value per call so that the work can be dealt out between matrix instructions.
+template <int HALF>
+struct SplitJob {
+    const f32x16 &src;
+    Parts3 &dst;
+    unsigned h0, m0, l0;
+    __device__ __forceinline__ SplitJob(const f32x16 &s, Parts3 &d) : src(s), dst(d), h0(0), m0(0), l0(0) {}
+    template <int K> __device__ __forceinline__ void step()
+    {
+        unsigned h, m, l;
+        split_value(src[8 * HALF + K], h, m, l);
+        if (K & 1) {
+            dst.hi[K >> 1] = upper_halves(h, h0); dst.mid[K >> 1] = upper_halves(m, m0); dst.lo[K >> 1] = upper_halves(l, l0);
+        } else {
+            h0 = h; m0 = m; l0 = l;
+        }
     }
-    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-    u32x4v ph, pm, pl;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {                      // upper halves of two dwords -> one dword (element 2q low)
-        ph[q] = __builtin_amdgcn_perm(h[2 * q + 1], h[2 * q], 0x07060302u);
-        pm[q] = __builtin_amdgcn_perm(m[2 * q + 1], m[2 * q], 0x07060302u);
-        pl[q] = __builtin_amdgcn_perm(l[2 * q + 1], l[2 * q], 0x07060302u);
+    __device__ __forceinline__ void all()
+    {
+        step<0>(); step<1>(); step<2>(); step<3>(); step<4>(); step<5>(); step<6>(); step<7>();
     }
-    Split3 r;
-    r.hi = __builtin_bit_cast(bf16x8, ph); r.mid = __builtin_bit_cast(bf16x8, pm); r.lo = __builtin_bit_cast(bf16x8, pl);
-    return r;
-}
+};
+struct NoJob { template <int K> __device__ __forceinline__ void step() {} };
+#ifdef DRONESIM_ABL_X3_NOSPLIT
+#define SplitJobInStage NoJobLike
+template <int HALF> struct NoJobLike {
+    __device__ __forceinline__ NoJobLike(const f32x16 &s, Parts3 &d) { d.hi[0] += (unsigned)s[8 * HALF]; }
+    template <int K> __device__ __forceinline__ void step() {}
+};
+#else
+#define SplitJobInStage SplitJob
+#endif
 
-// acc[t] += W * B[t] for every row tile, both operands in three parts: the six products, smallest first; the tiles
-// alternate so that consecutive matrix instructions never wait on each other's accumulator
-__device__ __forceinline__ void mfma6(f32x16 (&acc)[kTilesX], const bf16x8 (&w)[3], const Split3 (&b)[kTilesX])
+// LDS reads the compiler must NOT see: hipcc orders every LDS read it can see behind ALL pending global_load_lds of
+// the wave (s_waitcnt vmcnt(0)), which would drain the weight ring; the bytes read this way (biases, the x operand)
+// were written before the first DMA was issued.
+__device__ __forceinline__ uint32_t lds_addr(const void *p)
 {
-#pragma unroll
-    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[2], b[t].hi, acc[t], 0, 0, 0);    // lo * hi
-#pragma unroll
-    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[t].lo, acc[t], 0, 0, 0);    // hi * lo
-#pragma unroll
-    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], b[t].mid, acc[t], 0, 0, 0);   // mid * mid
-#pragma unroll
-    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[1], b[t].hi, acc[t], 0, 0, 0);    // mid * hi
-#pragma unroll
-    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[t].mid, acc[t], 0, 0, 0);   // hi * mid
-#pragma unroll
-    for (int t = 0; t < kTilesX; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[0], b[t].hi, acc[t], 0, 0, 0);    // hi * hi
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
 }
-
-// relu of a finished 32-feature chunk (its bias went in as the accumulator's initial value) -> k-step `s` (0 / 1) of
-// the next layer's B operand, three parts: registers 8 s .. 8 s + 7 of a lane are the k slots of k-step s.
-__device__ __forceinline__ Split3 chunk_to_operand(const f32x16 &acc, int s)
-{
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaxf(acc[8 * s + j], 0.0f);
-    return split3(v);
-}
-
-// The 32 biases of a chunk in accumulator layout (register 4 q + j of a lane = feature 8 q + 4 (lane >> 5) + j):
-// the initial value of the chunk's accumulators.  `bias` = the chunk's 32 floats in LDS.  The reads are inline asm ON
-// PURPOSE: hipcc orders every LDS read it can see behind ALL pending global_load_lds of the wave (s_waitcnt
-// vmcnt(0)), which would drain the weight ring twice per chunk; these bytes were written before the first DMA.
+// The 32 biases of a chunk in accumulator layout (register 4 q + j of a lane = feature 8 q + 4 (lane >> 5) + j): the
+// initial value of the chunk's accumulators.  `bias` = the chunk's 32 floats in LDS.
 __device__ __forceinline__ f32x16 bias_tile(const float *bias, int lane)
 {
-    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(bias + 4 * (lane >> 5));
+    const uint32_t addr = lds_addr(bias + 4 * (lane >> 5));
     float4 q0, q1, q2, q3;
     asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:32\n\tds_read_b128 %2, %4 offset:64\n\t"
                  "ds_read_b128 %3, %4 offset:96\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr) : "memory");
     return f32x16{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 }
+__device__ __forceinline__ Parts3 parts_from_lds(const char *p)      // hi | mid | lo, 1 KiB apart
+{
+    Parts3 r;
+    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r.hi), "=&v"(r.mid), "=&v"(r.lo) : "v"(lds_addr(p)) : "memory");
+    return r;
+}
+
+#define X3_MFMA(acc, w, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, as_bf16x8(b), acc, 0, 0, 0)
+#define X3_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef DRONESIM_ABL_X3_NOREAD
+#define X3_RING_READ(dst, p) (void)(p)
+#else
+#define X3_RING_READ(dst, p) dst = *reinterpret_cast<const bf16x8 *>(p)
+#endif
 
 __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int E, int N, int d_in, const MArgsX rest)
 {
@@ -701,24 +721,35 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
     int agent, row_block;
     xcd_work_item((a.E + kRowsX - 1) / kRowsX, agent, row_block);
     const int e0 = row_block * kRowsX;
-    const int NC1 = a.nc1, KS2 = 2 * a.nc1;
+    const int NC1 = a.nc1;
     const int nb = (a.nc1 + a.nc2) * 32;
     float *sbias = reinterpret_cast<float *>(smem);                // b1 | b2 (zero padded to chunks) | b3 (32)
-    float *spart = sbias + nb + 32;                                // [4 waves][kRowsX rows][33]
+    char *sxb = reinterpret_cast<char *>(sbias + nb + 32);         // x operand [tile][part][lane] x 16 B
+    float *spart = reinterpret_cast<float *>(sxb + kXbBytes);      // [4 waves][kRowsX rows][33], shares LDS with the rings
 
-    // ---- this lane's slice of the x operand per row tile: row 32 t + (lane & 31), inputs 8 (lane >> 5) .. + 7
-    Split3 xB[kTilesX];
-#pragma unroll
-    for (int t = 0; t < kTilesX; ++t) {
+    // ---- the x operand: row 32 t + (lane & 31), inputs 8 (lane >> 5) .. + 7, split once, kept in LDS (every wave uses it)
+    if (wave < kTilesX) {
+        const int t = wave;
         const int e = e0 + 32 * t + (lane & 31), k0 = 8 * (lane >> 5);
         const float *xr = a.x + ((size_t)min(e, a.E - 1) * a.N + agent) * a.d_in;
-        float v[8];
+        unsigned h[8], m[8], l[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xv = xr[min(k0 + j, a.d_in - 1)];          // clamped address, masked value: no branches
-            v[j] = (e < a.E && k0 + j < a.d_in) ? xv : 0.0f;
+            const float v = (e < a.E && k0 + j < a.d_in) ? xv : 0.0f;
+            h[j] = __float_as_uint(v);                             // (no relu on the inputs)
+            const float rem = v - __uint_as_float(h[j] & 0xffff0000u);
+            m[j] = __float_as_uint(rem);
+            l[j] = __float_as_uint(rem - __uint_as_float(m[j] & 0xffff0000u));
         }
-        xB[t] = split3(v);
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ph[q] = upper_halves(h[2 * q + 1], h[2 * q]); pm[q] = upper_halves(m[2 * q + 1], m[2 * q]);
+            pl[q] = upper_halves(l[2 * q + 1], l[2 * q]);
+        }
+        u32x4 *d = reinterpret_cast<u32x4 *>(sxb + t * 3072) + lane;
+        d[0] = ph; d[64] = pm; d[128] = pl;
     }
     uint32_t tval = 0, epval = 0;
     if (e0 + (tid >> 2) < a.E && a.fin.sample_kind != 0) {          // of the row this thread finishes (4 lanes per row)
@@ -734,9 +765,7 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
     }
     __syncthreads();
 
-    const bf16x8 *w1a = a.w1x + (size_t)agent * NC1 * 3 * 64 + lane;                  // [c1][part][lane]
-    const bf16x8 *w2a = a.w2x + (size_t)agent * a.nc2 * KS2 * 3 * 64 + lane;          // [c2][s][part][lane]
-    const bf16x8 *w3a = a.w3x + (size_t)agent * a.nc2 * 2 * 3 * 64 + lane;            // [s = 2 c2 + ss][part][lane]
+    const int nmine = (a.nc2 - wave + 3) / 4;                      // output chunks of this wave (wave-uniform): wave + 4 i
     f32x16 acc2[kMaxChunks][kTilesX];
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {                         // start from the layer-2 biases (zero padded)
@@ -744,101 +773,132 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
 #pragma unroll
         for (int t = 0; t < kTilesX; ++t) acc2[i][t] = b;
     }
-
-    // ---- stream over the chunks of the first hidden layer.  The weight fragments of this wave form ONE linear stream
-    //      of 3 KiB stages (the three parts of one (chunk, k-step)):  W1(c1), then W2(c1, ss, i) for ss < 2, i < nmine,
-    //      for every c1.  They travel global -> LDS by the DMA path (global_load_lds, 1 KiB per instruction) into a
-    //      ring PRIVATE to the wave, kRingX - 1 stages ahead of the matrix instructions, and are picked up by three
-    //      ds_read_b128 right before use: the look-ahead costs LDS instead of registers.  The ring needs no barrier
-    //      (one wave writes and reads it); what orders a read behind its DMA is the counted s_waitcnt vmcnt below.
-    const int nmine = (a.nc2 - wave + 3) / 4;                      // output chunks of this wave (wave-uniform)
-    char *ring = reinterpret_cast<char *>(spart) + (size_t)wave * kRingX * 3072;
-    int pc1 = 0, pss = 0, pi = -1, pslot = 0;                      // producer cursor: next stage to request (pi < 0: W1)
-    auto request = [&]() {
-        const bf16x8 *gp = pc1 >= NC1 ? w1a                        // past the end: a harmless re-read keeps the count
-                         : pi < 0 ? w1a + (size_t)pc1 * 3 * 64
-                                  : w2a + ((size_t)(wave + 4 * pi) * KS2 + 2 * pc1 + pss) * 3 * 64;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)p * 64),
-                                             (__attribute__((address_space(3))) void *)(ring + pslot * 3072 + p * 1024),
-                                             16, 0, 0);
-        pslot = pslot + 1 == kRingX ? 0 : pslot + 1;
-        if (++pi >= nmine) { pi = 0; if (++pss == 2) { pss = 0; pi = -1; ++pc1; } }
-    };
-    int cslot = 0;
-    auto take = [&](bf16x8 (&dst)[3]) {                            // the oldest requested stage -> registers
-#ifdef DRONESIM_ABL_X3_NOLOAD
-#pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p] = xB[0].hi + (short)cslot;
-#else
-#ifndef DRONESIM_ABL_X3_NODMA
-        request();                                                 // into the slot the previous take() emptied
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (kRingX - 1)) : "memory");
-#endif
-#ifdef DRONESIM_ABL_X3_NOREAD
-#pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p] = xB[0].hi + (short)cslot;
-#else
-        const char *sp = ring + cslot * 3072 + lane * 16;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) dst[p] = *reinterpret_cast<const bf16x8 *>(sp + p * 1024);
-#endif
-#endif
-        cslot = cslot + 1 == kRingX ? 0 : cslot + 1;
-    };
-    if (nmine > 0) {
-#pragma unroll 1
-        for (int j = 0; j < kRingX - 1; ++j) request();
-        for (int c1 = 0; c1 < NC1; ++c1) {
-            f32x16 a1[kTilesX];
-            a1[0] = bias_tile(sbias + c1 * 32, lane);
-#pragma unroll
-            for (int t = 1; t < kTilesX; ++t) a1[t] = a1[0];
-            bf16x8 wf[3];
-            take(wf);
-            mfma6(a1, wf, xB);                                     // layer 1, chunk c1 (one k-step of 16 inputs)
-#pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                Split3 hB[kTilesX];
-#pragma unroll
-#ifdef DRONESIM_ABL_X3_NOSPLIT
-                for (int t = 0; t < kTilesX; ++t) { hB[t] = xB[t]; hB[t].hi[0] += (short)a1[t][8 * ss]; }
-#else
-                for (int t = 0; t < kTilesX; ++t) hB[t] = chunk_to_operand(a1[t], ss);
-#endif
-#pragma unroll
-                for (int i = 0; i < kMaxChunks; ++i) {
-                    if (i < nmine) {                               // wave-uniform
-                        take(wf);
-                        mfma6(acc2[i], wf, hB);
-                    }
-                }
-            }
-        }
-    }
-
-    // ---- layer 3 from the finished layer-2 accumulators
     f32x16 y[kTilesX];
 #pragma unroll
     for (int t = 0; t < kTilesX; ++t) y[t] = f32x16{};
+
+    // ---- The weight fragments of this wave form ONE linear stream of 3 KiB stages (the three parts of one 32-feature
+    //      chunk x 16 k slots), laid out by the host in the order the matrix instructions want them (include/dronesim.h):
+    //          W1(0), W2(0,0,*) | W1(1), W2(0,1,*), W2(1,0,*) | W1(2), W2(1,1,*), W2(2,0,*) | ... | W3(*)
+    //      (W2(c1, ss, i): k-step 2 c1 + ss of this wave's i-th output chunk).  They travel global -> LDS by DMA
+    //      (global_load_lds, 1 KiB per instruction) into a ring PRIVATE to the wave, requested kRingX stages before
+    //      their matrix instructions and picked up part by part during the PREVIOUS stage's matrix instructions, into
+    //      the registers that stage has just finished with: no copies, no exposed LDS or L2 latency.  The ring needs no
+    //      barrier (one wave writes and reads it); a read is ordered behind its DMA by the counted s_waitcnt vmcnt.
+    //      The stream is padded by kRingX stages, so the producer never needs to know where it ends.
+    char *ring = reinterpret_cast<char *>(spart) + (size_t)wave * kRingX * 3072;
+    const bf16x8 *gp = a.ws + ((size_t)agent * 4 + wave) * a.stages * 192 + lane;
+    int pslot = 0;
+    auto request_part = [&](int p) {                               // 1 KiB of the stage kRingX ahead
+#ifdef DRONESIM_ABL_X3_ONEPART
+        if (p != 0) return;
+#endif
+#ifndef DRONESIM_ABL_X3_NODMA
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)p * 64),
+                                         (__attribute__((address_space(3))) void *)(ring + pslot * 3072 + p * 1024), 16, 0, 0);
+#endif
+    };
+    auto request_done = [&]() {
+#ifndef DRONESIM_ABL_X3_SAMEADDR
+        gp += 192;
+#endif
+        pslot = pslot + 1 == kRingX ? 0 : pslot + 1;
+    };
+    auto request = [&]() { request_part(0); request_part(1); request_part(2); request_done(); };
+    bf16x8 wf[3];                                                  // the current stage's fragments (hi, mid, lo)
+    int nslot = 1;                                                 // ring slot of the NEXT stage
+    // one stage: acc[t] += W * B[t], both operands in three parts = six products per tile, smallest first as far as the
+    // register hand-over allows (lo.hi, mid.mid, hi.lo, mid.hi, hi.mid, hi.hi); `job` gets one call per slot 1..8
+    auto stage = [&](f32x16 (&acc)[kTilesX], const Parts3 (&b)[kTilesX], auto &job) {
+        #ifdef DRONESIM_ABL_X3_ONEPART
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kRingX - 2) : "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (kRingX - 2)) : "memory");    // the NEXT stage has landed
+#endif
+        const char *np = ring + nslot * 3072 + lane * 16;
+        X3_PIN();
+        X3_MFMA(acc[0], wf[2], b[0].hi);  X3_PIN();
+        X3_MFMA(acc[1], wf[2], b[1].hi);  X3_PIN();
+        X3_RING_READ(wf[2], np + 2048); job.template step<0>(); X3_PIN();
+        X3_MFMA(acc[0], wf[1], b[0].mid); X3_PIN(); job.template step<1>(); X3_PIN();
+        X3_MFMA(acc[1], wf[1], b[1].mid); X3_PIN(); request_part(0); job.template step<2>(); X3_PIN();
+        X3_MFMA(acc[0], wf[0], b[0].lo);  X3_PIN(); job.template step<3>(); X3_PIN();
+        X3_MFMA(acc[1], wf[0], b[1].lo);  X3_PIN(); job.template step<4>(); X3_PIN();
+        X3_MFMA(acc[0], wf[1], b[0].hi);  X3_PIN(); request_part(1); job.template step<5>(); X3_PIN();
+        X3_MFMA(acc[1], wf[1], b[1].hi);  X3_PIN();
+        X3_RING_READ(wf[1], np + 1024); job.template step<6>(); X3_PIN();
+        X3_MFMA(acc[0], wf[0], b[0].mid); X3_PIN(); job.template step<7>(); X3_PIN();
+        X3_MFMA(acc[1], wf[0], b[1].mid); X3_PIN();
+        request_part(2); request_done();                           // the stage kRingX ahead, into the slot this stage came from
+        X3_PIN();
+        X3_MFMA(acc[0], wf[0], b[0].hi);  X3_PIN();
+        X3_MFMA(acc[1], wf[0], b[1].hi);  X3_PIN();
+        X3_RING_READ(wf[0], np);
+        nslot = nslot + 1 == kRingX ? 0 : nslot + 1;
+        X3_PIN();
+    };
+
+    if (nmine > 0) {
+#pragma unroll 1
+        for (int j = 0; j < kRingX; ++j) request();
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (kRingX - 1)) : "memory");
 #pragma unroll
-    for (int i = 0; i < kMaxChunks; ++i) {
-        const int c2 = wave + 4 * i;
-        if (c2 < a.nc2) {
+        for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const bf16x8 *>(ring + p * 1024 + lane * 16);
+
+        NoJob nojob;
+        f32x16 a1[kTilesX];
+        Parts3 hB0[kTilesX], hB1[kTilesX];                         // layer-2 operands of k-steps 2 c1 and 2 c1 + 1
+        {                                                          // layer 1, chunk 0
+            Parts3 xB[kTilesX];
 #pragma unroll
-            for (int ss = 0; ss < 2; ++ss) {
-                const bf16x8 *wp = w3a + ((size_t)(2 * c2 + ss)) * 3 * 64;
-                bf16x8 wf[3];
+            for (int t = 0; t < kTilesX; ++t) { a1[t] = bias_tile(sbias, lane); xB[t] = parts_from_lds(sxb + t * 3072 + lane * 16); }
+            stage(a1, xB, nojob);
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wf[p] = wp[(size_t)p * 64];
-                Split3 pB[kTilesX];
+            for (int t = 0; t < kTilesX; ++t) { SplitJob<0> j(a1[t], hB0[t]); j.all(); }
+        }
+        for (int c1 = 0; c1 < NC1; ++c1) {
+            // k-step 2 c1 of every chunk of mine; meanwhile the other half of a1 becomes hB1 (tile i in stage i)
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) pB[t] = chunk_to_operand(acc2[i][t], ss);
-                mfma6(y, wf, pB);
+            for (int i = 0; i < kMaxChunks; ++i) {
+                if (i < nmine) {                                   // wave-uniform
+                    if (i < kTilesX) { SplitJobInStage<1> j(a1[i], hB1[i]); stage(acc2[i], hB0, j); }
+                    else stage(acc2[i], hB0, nojob);
+                }
+            }
+            if (nmine < kTilesX) { SplitJob<1> j(a1[1], hB1[1]); j.all(); }
+            if (c1 + 1 < NC1) {                                    // layer 1 of the next chunk
+                Parts3 xB[kTilesX];
+                a1[0] = bias_tile(sbias + (c1 + 1) * 32, lane);
+#pragma unroll
+                for (int t = 0; t < kTilesX; ++t) { a1[t] = a1[0]; xB[t] = parts_from_lds(sxb + t * 3072 + lane * 16); }
+                stage(a1, xB, nojob);
+            }
+            // k-step 2 c1 + 1; meanwhile the first half of the next chunk becomes hB0 (stale and unused after the last chunk)
+#pragma unroll
+            for (int i = 0; i < kMaxChunks; ++i) {
+                if (i < nmine) {
+                    if (i < kTilesX) { SplitJobInStage<0> j(a1[i], hB0[i]); stage(acc2[i], hB1, j); }
+                    else stage(acc2[i], hB1, nojob);
+                }
+            }
+            if (nmine < kTilesX) { SplitJob<0> j(a1[1], hB0[1]); j.all(); }
+        }
+
+        // ---- layer 3 from the finished layer-2 accumulators, same stream
+#pragma unroll
+        for (int i = 0; i < kMaxChunks; ++i) {
+            if (i < nmine) {
+                Parts3 pB[kTilesX];
+#pragma unroll
+                for (int t = 0; t < kTilesX; ++t) { SplitJob<0> j(acc2[i][t], pB[t]); j.all(); }
+                stage(y, pB, nojob);
+#pragma unroll
+                for (int t = 0; t < kTilesX; ++t) { SplitJob<1> j(acc2[i][t], pB[t]); j.all(); }
+                stage(y, pB, nojob);
             }
         }
     }
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the partial sums reuse the rings: no DMA may land late
     __syncthreads();
 #pragma unroll
@@ -867,6 +927,9 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
         finish_quad(a.fin, yv, e, agent, part, tval, epval);
     }
 }
+#undef X3_MFMA
+#undef X3_PIN
+#undef X3_RING_READ
 
 // > 64 KiB of dynamic LDS must be opted into once per (kernel, device): a bit mask of device ordinals per kernel,
 // guarded by a mutex (the library may be driven from several host threads / devices of one process)
@@ -974,6 +1037,13 @@ extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, 
     return DRONESIM_OK;
 }
 
+// stages per (agent, wave) stream: wave 0 owns the most chunks; + kRingX of padding for the run-ahead requests
+extern "C" int dronesim_mlp_bf16x3_stages(int h1, int h2)
+{
+    const int nc1 = (h1 + 31) / 32, nc2 = (h2 + 31) / 32, nm = (nc2 + 3) / 4;
+    return nc1 * (1 + 2 * nm) + 2 * nm + kRingX;
+}
+
 extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                                            uint64_t seed, uint64_t counter, int64_t env_base,
                                            const int32_t *t, const int32_t *episode, int E, void *stream)
@@ -982,18 +1052,21 @@ extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x
     const int rc = check_mlp("bf16x3", m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
     if (rc) return rc;
     if (m->d_in > 16) return dronesim_fail(DRONESIM_EUNSUPPORTED, "bf16x3 path: d_in <= 16");
-    if (!m->w1p || !m->w2p || !m->w3p || !m->b1 || !m->b2 || !m->b3)
+    if (!m->w1p || !m->b1 || !m->b2 || !m->b3)
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16x3: NULL weight array");
     if (E == 0) return DRONESIM_OK;
     MArgsX a{};
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2;
     a.nc1 = (m->h1 + 31) / 32; a.nc2 = (m->h2 + 31) / 32;
+    a.stages = dronesim_mlp_bf16x3_stages(m->h1, m->h2);
+    if (m->reserved != a.stages)
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16x3: DroneMlpBf16.reserved must hold "
+                                              "dronesim_mlp_bf16x3_stages(h1, h2), the stages per stream of w1p");
     a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
-    a.w1x = reinterpret_cast<const bf16x8 *>(m->w1p); a.w2x = reinterpret_cast<const bf16x8 *>(m->w2p);
-    a.w3x = reinterpret_cast<const bf16x8 *>(m->w3p);
+    a.ws = reinterpret_cast<const bf16x8 *>(m->w1p);
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
     const size_t part_bytes = sizeof(float) * 4 * kRowsX * 33, ring_bytes = (size_t)4 * kRingX * 3072;   // the two share LDS
-    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32) + (part_bytes > ring_bytes ? part_bytes : ring_bytes);
+    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32) + kXbBytes + (part_bytes > ring_bytes ? part_bytes : ring_bytes);
     hipLaunchKernelGGL(mlp3_bf16x3_kernel, dim3(((E + kRowsX - 1) / kRowsX) * m->N), dim3(256), lds,
                        static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();

@@ -98,6 +98,37 @@ def stack_reference_modules(modules, kind=None):
     return st(w1), st(b1), st(w2), st(b2), st(w3), st(b3), OUT_TANH_SIGMOID, SAMPLE_GAUSSIAN
 
 
+def pack_bf16x3_streams(w1, w2, w3, stages):
+    """The weight image of `dronesim_mlp_forward_bf16x3` (include/dronesim.h): per (agent, wave) one stream of
+    `stages` 3 KiB stages -- hi | mid | lo fragments of one (chunk, k-step) -- in the kernel's consumption order.
+    Returns ``[N, 4, stages, 3, 64, 8]`` bf16."""
+    import torch
+    n, _, h1 = w1.shape
+    h2 = w2.shape[2]
+    nc1, nc2 = (h1 + 31) // 32, (h2 + 31) // 32
+    f1 = pack_bf16x3_fragments(w1, 1, nc1, "linear").reshape(n, nc1, 3, 64, 8)                    # [c1]
+    f2 = pack_bf16x3_fragments(w2, 2 * nc1, nc2, "accumulator").reshape(n, nc2 * 2 * nc1, 3, 64, 8)  # [c2 * KS2 + s]
+    f3 = pack_bf16x3_fragments(w3, 2 * nc2, 1, "accumulator").reshape(n, 2 * nc2, 3, 64, 8)       # [s]
+    table = torch.cat([f1, f2, f3, torch.zeros_like(f1[:, :1])], dim=1)
+    o2, o3, zero = nc1, nc1 + nc2 * 2 * nc1, nc1 + nc2 * 2 * nc1 + 2 * nc2
+    streams = []
+    for w in range(4):
+        mine = list(range(w, nc2, 4))
+        w2i = lambda c1, ss: [o2 + c2 * 2 * nc1 + 2 * c1 + ss for c2 in mine]
+        seq = [0]
+        for c1 in range(nc1):
+            seq += w2i(c1, 0)
+            if c1 + 1 < nc1:
+                seq.append(c1 + 1)
+            seq += w2i(c1, 1)
+        for c2 in mine:
+            seq += [o3 + 2 * c2, o3 + 2 * c2 + 1]
+        assert len(seq) <= stages
+        streams.append(seq + [zero] * (stages - len(seq)))
+    idx = torch.tensor(streams, device=table.device)                                             # [4, stages]
+    return table[:, idx].contiguous()
+
+
 class BatchedMLP:
     def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0, precision="f32"):
         """w1 [N,d_in,h1], b1 [N,h1], w2 [N,h1,h2], b2 [N,h2], w3 [N,h2,nout], b3 [N,nout] (float32).
@@ -142,14 +173,12 @@ class BatchedMLP:
         elif precision == "bf16x3":
             if self.d_in > 16:
                 raise ValueError("the bf16x3 path supports d_in <= 16")
-            nc1, nc2 = (self.h1 + 31) // 32, (self.h2 + 31) // 32
-            self._w1p = pack_bf16x3_fragments(self.w1, 1, nc1, "linear")
-            self._w2p = pack_bf16x3_fragments(self.w2, 2 * nc1, nc2, "accumulator")
-            self._w3p = pack_bf16x3_fragments(self.w3, 2 * nc2, 1, "accumulator")
+            stages = int(self._lib.dronesim_mlp_bf16x3_stages(self.h1, self.h2))
+            self._w1p = pack_bf16x3_streams(self.w1, self.w2, self.w3, stages)
             mb = _native.DroneMlpBf16()
             mb.N, mb.d_in, mb.h1, mb.h2, mb.nout = self.n_agents, self.d_in, self.h1, self.h2, self.nout
-            mb.out_kind, mb.sample_kind = self.out_kind, self.sample_kind
-            mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), self._w2p.data_ptr(), self._w3p.data_ptr()
+            mb.out_kind, mb.sample_kind, mb.reserved = self.out_kind, self.sample_kind, stages
+            mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), None, None
             mb.b1, mb.b2, mb.b3 = self.b1.data_ptr(), self.b2.data_ptr(), self.b3.data_ptr()
             self._m = mb
         elif precision != "f32":
