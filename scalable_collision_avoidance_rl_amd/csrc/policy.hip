@@ -601,14 +601,23 @@ __global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const 
 // k-step of 16 cost 6/16 of the matrix time of the eight v_mfma_f32_32x32x2_f32 they replace; the result meets the
 // reference's own torch modules to the 1e-5 bar like the exact-f32 kernel (tools/split_bf16_emulation.py: a two-part
 // split with three products does NOT -- 4-5x over the bar on the Gaussian and critic heads).
-// Weights are split and packed per fragment on the host (policies.py), [agent][chunk][k-step][part][64 lanes] x 16 B.
+// Weights are split and packed per fragment on the host (policies.py) into one consumption-ordered stream per
+// (agent, wave) (include/dronesim.h).
 // The three layers are fused in REGISTERS, transposed like the bf16 kernel (D[feature][env row]): one workgroup =
-// 32 env rows of one agent, 4 waves; wave w owns the output chunks w, w+4, ... of layer 2 and keeps their
-// accumulators for the whole launch while it streams over the first hidden layer chunk by chunk -- each chunk of h1 is
-// computed where it is consumed (layer 1 has K = d_in <= 16: one k-step), bias + relu + split happen on the
-// accumulator registers, whose layout IS a valid B operand once the k order of W2 / W3 is permuted to match on the
-// host ("accumulator" order, include/dronesim.h).  No activation ever touches LDS; the only barrier is the final
-// sum of the four waves' layer-3 partials.  Non-finite activations are outside the split's domain (inf - inf).
+// 64 env rows (two 32-row tiles) of one agent, 4 waves; wave w owns the output chunks w, w+4, ... of layer 2 and keeps
+// their accumulators for the whole launch while it streams over the first hidden layer chunk by chunk -- each chunk of
+// h1 is computed where it is consumed (layer 1 has K = d_in <= 16: one k-step), relu + split happen on the accumulator
+// registers (the bias went in as their initial value), whose layout IS a valid B operand once the k order of W2 / W3
+// is permuted to match on the host ("accumulator" order, include/dronesim.h).  No activation ever touches LDS; the
+// only barriers are around the final sum of the four waves' layer-3 partials.  Non-finite activations are outside the
+// split's domain (inf - inf).
+// The kernel is software-pipelined by hand inside each wave (mlp3_bf16x3_kernel: `stage`): between the twelve matrix
+// instructions of a stage sit the LDS reads of the NEXT stage's fragments, the DMA requests of the stage four ahead and
+// one row tile's share of the relu + split that the stages after the next layer-1 step will consume -- a wave never
+// waits on L2, LDS or its own vector work with the matrix pipe idle.  Measured on the MI355X (tools/trace_x3.py,
+// tools/micro/mfma_dma.hip): the matrix pipe is ~70 % busy at the ACTUAL shader clock, and that clock is what gives:
+// 2.07 GHz with the weight stream switched off, 1.6 GHz with it on (power management), against 2.4 GHz nominal --
+// ring depth 3 / 4 / 5, spreading the roles over the SIMDs and L1-resident weights all leave the time unchanged.
 constexpr int kTilesX = 2;                 // row tiles per wave: every weight fragment loaded feeds 12 matrix instructions
 constexpr int kRowsX = 32 * kTilesX;       // env rows per workgroup
 constexpr int kRingX = 4;                  // stages of the per-wave weight ring in LDS (3 KiB each)
@@ -619,6 +628,9 @@ struct MArgsX {
     const float *x, *b1, *b2, *b3;
     const bf16x8 *ws;              // the per-(agent, wave) fragment streams
     int stages;                    // stages per stream (padded)
+#if defined(DRONESIM_TRACE)
+    long long *trace;              // developer builds only
+#endif
     FinishArgs fin;
 };
 
@@ -723,6 +735,12 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
     const int e0 = row_block * kRowsX;
     const int NC1 = a.nc1;
     const int nb = (a.nc1 + a.nc2) * 32;
+#ifdef DRONESIM_TRACE
+    if (a.trace && lane == 0) {                                    // shader clock and the 100 MHz clock at entry
+        a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 0] = __builtin_amdgcn_s_memtime();
+        a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     float *sbias = reinterpret_cast<float *>(smem);                // b1 | b2 (zero padded to chunks) | b3 (32)
     char *sxb = reinterpret_cast<char *>(sbias + nb + 32);         // x operand [tile][part][lane] x 16 B
     float *spart = reinterpret_cast<float *>(sxb + kXbBytes);      // [4 waves][kRowsX rows][33], shares LDS with the rings
@@ -900,6 +918,12 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the partial sums reuse the rings: no DMA may land late
+#ifdef DRONESIM_TRACE
+    if (a.trace && lane == 0) {                                    // ... and when this wave's stream is done
+        a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
+        a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < kTilesX; ++t)
@@ -1064,6 +1088,9 @@ extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x
                                               "dronesim_mlp_bf16x3_stages(h1, h2), the stages per stream of w1p");
     a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
     a.ws = reinterpret_cast<const bf16x8 *>(m->w1p);
+#if defined(DRONESIM_TRACE)
+    a.trace = g_policy_trace;
+#endif
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
     const size_t part_bytes = sizeof(float) * 4 * kRowsX * 33, ring_bytes = (size_t)4 * kRingX * 3072;   // the two share LDS
     const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32) + kXbBytes + (part_bytes > ring_bytes ? part_bytes : ring_bytes);
