@@ -120,9 +120,9 @@ def main():
     ap.add_argument("--policy", default="random", choices=["random", "softmax16", "gaussian"],
                     help="action source: pre-generated U(-1,1) actions (the graded workload) or a batched per-agent "
                          "policy evaluated on the env's observation every step (BASELINE configs[4] uses 'gaussian')")
-    ap.add_argument("--policy-precision", default="f32", choices=["f32", "bf16x3", "bf16"],
-                    help="matrix-core arithmetic of the batched policy (f32 = exact; bf16x3 = three-part split on "
-                         "the bf16 instructions, float32-accurate; bf16 = opt-in fast path, ~1e-2)")
+    ap.add_argument("--policy-precision", default="f32", choices=["f32", "bf16x3", "f16x2", "bf16"],
+                    help="matrix-core arithmetic of the batched policy (f32 = exact; bf16x3 / f16x2 = three-part bf16 / "
+                         "two-part float16 split, float32-accurate; bf16 = opt-in fast path, ~1e-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()

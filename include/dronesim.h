@@ -320,6 +320,17 @@ int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *ou
                                 uint64_t seed, uint64_t counter, int64_t env_base,
                                 const int32_t *t, const int32_t *episode, int E, void *stream);
 
+/* The same with a two-part float16 split ("f16x2"): v = hi + lo with hi = float16(v), lo = float16(v - hi), exact to
+ * 2^-22 of v (the float16 matrix instruction honours subnormal parts), and a product is the float32 sum of hi*hi,
+ * hi*lo, lo*hi (the rest is below 2^-22 of the product): float32-level agreement with dronesim_mlp_forward (same 1e-5
+ * bar) at 3/16 of its matrix time and 2/3 of the weight bytes of bf16x3.  DOMAIN: every weight, input and hidden
+ * activation must be below 65504 in magnitude (float16 range) -- beyond it the result is inf / NaN; use bf16x3 or
+ * dronesim_mlp_forward for such networks.  Weight image as for bf16x3 with two float16 parts per stage:
+ * [N][4][S][2][64][8] float16, 2 KiB per stage.  */
+int dronesim_mlp_forward_f16x2(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                               uint64_t seed, uint64_t counter, int64_t env_base,
+                               const int32_t *t, const int32_t *episode, int E, void *stream);
+
 const char *dronesim_last_error(void);
 const char *dronesim_error_string(int code);
 int dronesim_version(void);

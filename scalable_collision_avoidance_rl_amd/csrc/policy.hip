@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <mutex>
+#include <type_traits>
 
 #include "common.hpp"
 #include "dronesim.h"
@@ -618,15 +619,14 @@ __global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const 
 // tools/micro/mfma_dma.hip): the matrix pipe is ~70 % busy at the ACTUAL shader clock, and that clock is what gives:
 // 2.07 GHz with the weight stream switched off, 1.6 GHz with it on (power management), against 2.4 GHz nominal --
 // ring depth 3 / 4 / 5, spreading the roles over the SIMDs and L1-resident weights all leave the time unchanged.
-constexpr int kTilesX = 2;                 // row tiles per wave: every weight fragment loaded feeds 12 matrix instructions
+constexpr int kTilesX = 2;                 // row tiles per wave: every weight fragment loaded feeds all of them
 constexpr int kRowsX = 32 * kTilesX;       // env rows per workgroup
-constexpr int kRingX = 4;                  // stages of the per-wave weight ring in LDS (3 KiB each)
-constexpr int kXbBytes = kTilesX * 3 * 64 * 16;   // the split x operand of the workgroup in LDS
+constexpr int kRingX = 4;                  // stages of the per-wave weight ring in LDS
 
 struct MArgsX {
     int E, N, d_in, h1, h2, nc1, nc2;
     const float *x, *b1, *b2, *b3;
-    const bf16x8 *ws;              // the per-(agent, wave) fragment streams
+    const char *ws;                // the per-(agent, wave) fragment streams
     int stages;                    // stages per stream (padded)
 #if defined(DRONESIM_TRACE)
     long long *trace;              // developer builds only
@@ -635,55 +635,94 @@ struct MArgsX {
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-struct Parts3 { u32x4 hi, mid, lo; };      // the three bf16 parts of a lane's 8 k-slots (two per dword, low half first)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+template <int P> struct Parts { u32x4 p[P]; };     // the P parts of a lane's 8 k-slots (two 16-bit values per dword, low half first)
 
-__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 &v) { return __builtin_bit_cast(bf16x8, v); }
-
-// One float32 -> the bit patterns whose upper halves are its three bf16 parts (truncation: the upper 16 bits of a
-// float32 ARE a bf16; v = hi + mid + lo exactly).  5 vector instructions with the relu.
-__device__ __forceinline__ void split_value(float v, unsigned &h, unsigned &m, unsigned &l)
-{
-    v = fmaxf(v, 0.0f);
-    h = __float_as_uint(v);
-    const float rem = v - __uint_as_float(h & 0xffff0000u);
-    m = __float_as_uint(rem);
-    l = __float_as_uint(rem - __uint_as_float(m & 0xffff0000u));
-}
 __device__ __forceinline__ unsigned upper_halves(unsigned odd, unsigned even)      // -> {even.hi16 (low), odd.hi16 (high)}
 {
     return __builtin_amdgcn_perm(odd, even, 0x07060302u);
 }
 
-// relu + split of half an accumulator tile (registers 8 HALF .. 8 HALF + 7 = the k slots of k-step HALF of the next
-// layer's B operand), one value per call so that the work can be dealt out between matrix instructions.
-template <int HALF>
-struct SplitJob {
-    const f32x16 &src;
-    Parts3 &dst;
-    unsigned h0, m0, l0;
-    __device__ __forceinline__ SplitJob(const f32x16 &s, Parts3 &d) : src(s), dst(d), h0(0), m0(0), l0(0) {}
-    template <int K> __device__ __forceinline__ void step()
+// ---- the two split schemes.  A scheme names its parts (part 0 = the leading one), the partial products it keeps, in
+//      issue order -- smallest first as far as the register hand-over of the weight fragments allows: a fragment part is
+//      re-loaded with the NEXT stage's bytes right behind its last product -- and how two float32 values become one
+//      dword of every part.
+struct SchemeBf16x3 {                                  // v = hi + mid + lo exactly (truncation), products >= 2^-16
+    static constexpr int kParts = 3, kProducts = 6;
+    __device__ static constexpr int w_part(int q) { constexpr int t[6] = {2, 1, 0, 1, 0, 0}; return t[q]; }   // lo.hi mid.mid hi.lo
+    __device__ static constexpr int b_part(int q) { constexpr int t[6] = {0, 1, 2, 0, 1, 0}; return t[q]; }   // mid.hi hi.mid hi.hi
+    __device__ static constexpr int last_use(int p) { constexpr int t[3] = {5, 3, 0}; return t[p]; }
+    __device__ static constexpr int request_slot(int p) { constexpr int t[3] = {3, 6, 9}; return t[p]; }
+    __device__ static __forceinline__ f32x16 mfma(const u32x4 &w, const u32x4 &b, const f32x16 &acc)
     {
-        unsigned h, m, l;
-        split_value(src[8 * HALF + K], h, m, l);
-        if (K & 1) {
-            dst.hi[K >> 1] = upper_halves(h, h0); dst.mid[K >> 1] = upper_halves(m, m0); dst.lo[K >> 1] = upper_halves(l, l0);
-        } else {
-            h0 = h; m0 = m; l0 = l;
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    // the upper 16 bits of a float32 ARE a bf16: 5 vector instructions per value with the relu, 3 per pair to pack
+    template <bool RELU> __device__ static __forceinline__ void split_pair(float v0, float v1, unsigned (&d)[3])
+    {
+        if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+        const unsigned h0 = __float_as_uint(v0), h1 = __float_as_uint(v1);
+        const float r0 = v0 - __uint_as_float(h0 & 0xffff0000u), r1 = v1 - __uint_as_float(h1 & 0xffff0000u);
+        const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+        const float l0 = r0 - __uint_as_float(m0 & 0xffff0000u), l1 = r1 - __uint_as_float(m1 & 0xffff0000u);
+        d[0] = upper_halves(h1, h0); d[1] = upper_halves(m1, m0); d[2] = upper_halves(__float_as_uint(l1), __float_as_uint(l0));
+    }
+};
+struct SchemeF16x2 {                                   // v = hi + lo to 2^-22 (float16 parts, subnormals honoured by the
+    static constexpr int kParts = 2, kProducts = 3;    // matrix unit), products hi.hi, hi.lo, lo.hi; |v| < 65504
+    __device__ static constexpr int w_part(int q) { constexpr int t[3] = {1, 0, 0}; return t[q]; }            // lo.hi hi.lo hi.hi
+    __device__ static constexpr int b_part(int q) { constexpr int t[3] = {0, 1, 0}; return t[q]; }
+    __device__ static constexpr int last_use(int p) { constexpr int t[2] = {2, 0}; return t[p]; }
+    __device__ static constexpr int request_slot(int p) { constexpr int t[2] = {2, 4}; return t[p]; }
+    __device__ static __forceinline__ f32x16 mfma(const u32x4 &w, const u32x4 &b, const f32x16 &acc)
+    {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+    template <bool RELU> __device__ static __forceinline__ void split_pair(float v0, float v1, unsigned (&d)[2])
+    {
+        if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);                   // any rounding will do: v - hi is exact
+        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h[0], v1 - (float)h[1]);
+        d[0] = __builtin_bit_cast(unsigned, h); d[1] = __builtin_bit_cast(unsigned, l);
+    }
+};
+
+// relu + split of half an accumulator tile (registers 8 HALF .. 8 HALF + 7 = the k slots of k-step HALF of the next
+// layer's B operand), dealt out over the slots between a stage's matrix instructions: one call per slot.
+template <class S, int HALF>
+struct SplitJob {
+    static constexpr int kSlots = 2 * S::kProducts;
+    const f32x16 &src;
+    Parts<S::kParts> &dst;
+    __device__ __forceinline__ SplitJob(const f32x16 &s, Parts<S::kParts> &d) : src(s), dst(d) {}
+    template <int Q> __device__ __forceinline__ void pair()                        // values 2 Q, 2 Q + 1 -> dword Q
+    {
+        unsigned d[S::kParts];
+        S::template split_pair<true>(src[8 * HALF + 2 * Q], src[8 * HALF + 2 * Q + 1], d);
+#pragma unroll
+        for (int p = 0; p < S::kParts; ++p) dst.p[p][Q] = d[p];
+    }
+    template <int SLOT> __device__ __forceinline__ void slot()
+    {
+        if constexpr (kSlots >= 12) {                  // twelve slots: a pair behind slots 1, 3, 5, 7
+            if constexpr (SLOT == 1) pair<0>();
+            if constexpr (SLOT == 3) pair<1>();
+            if constexpr (SLOT == 5) pair<2>();
+            if constexpr (SLOT == 7) pair<3>();
+        } else {                                       // six slots: a pair behind slots 1 .. 4
+            if constexpr (SLOT >= 1 && SLOT <= 4) pair<SLOT - 1>();
         }
     }
-    __device__ __forceinline__ void all()
-    {
-        step<0>(); step<1>(); step<2>(); step<3>(); step<4>(); step<5>(); step<6>(); step<7>();
-    }
+    __device__ __forceinline__ void all() { pair<0>(); pair<1>(); pair<2>(); pair<3>(); }
 };
-struct NoJob { template <int K> __device__ __forceinline__ void step() {} };
+struct NoJob { template <int SLOT> __device__ __forceinline__ void slot() {} };
 #ifdef DRONESIM_ABL_X3_NOSPLIT
-#define SplitJobInStage NoJobLike
-template <int HALF> struct NoJobLike {
-    __device__ __forceinline__ NoJobLike(const f32x16 &s, Parts3 &d) { d.hi[0] += (unsigned)s[8 * HALF]; }
-    template <int K> __device__ __forceinline__ void step() {}
+template <class S, int HALF> struct NoSplitJob {
+    __device__ __forceinline__ NoSplitJob(const f32x16 &s, Parts<S::kParts> &d) { d.p[0][0] += (unsigned)s[8 * HALF]; }
+    template <int SLOT> __device__ __forceinline__ void slot() {}
 };
+#define SplitJobInStage NoSplitJob
 #else
 #define SplitJobInStage SplitJob
 #endif
@@ -706,24 +745,29 @@ __device__ __forceinline__ f32x16 bias_tile(const float *bias, int lane)
                  : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3) : "v"(addr) : "memory");
     return f32x16{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
 }
-__device__ __forceinline__ Parts3 parts_from_lds(const char *p)      // hi | mid | lo, 1 KiB apart
+template <int P> __device__ __forceinline__ Parts<P> parts_from_lds(const char *p)      // parts 1 KiB apart
 {
-    Parts3 r;
-    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(r.hi), "=&v"(r.mid), "=&v"(r.lo) : "v"(lds_addr(p)) : "memory");
+    Parts<P> r;
+    if constexpr (P == 3)
+        asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:1024\n\tds_read_b128 %2, %3 offset:2048\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r.p[0]), "=&v"(r.p[1]), "=&v"(r.p[2]) : "v"(lds_addr(p)) : "memory");
+    else
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(r.p[0]), "=&v"(r.p[1]) : "v"(lds_addr(p)) : "memory");
     return r;
 }
 
-#define X3_MFMA(acc, w, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, as_bf16x8(b), acc, 0, 0, 0)
 #define X3_PIN() __builtin_amdgcn_sched_barrier(0)
 #ifdef DRONESIM_ABL_X3_NOREAD
 #define X3_RING_READ(dst, p) (void)(p)
 #else
-#define X3_RING_READ(dst, p) dst = *reinterpret_cast<const bf16x8 *>(p)
+#define X3_RING_READ(dst, p) dst = *reinterpret_cast<const u32x4 *>(p)
 #endif
 
-__global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int E, int N, int d_in, const MArgsX rest)
+template <class S>
+__global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int E, int N, int d_in, const MArgsX rest)
 {
+    constexpr int P = S::kParts, kStageBytes = P * 1024;
     MArgsX a = rest;
     a.x = x; a.E = E; a.N = N; a.d_in = d_in;
     constexpr int kMaxChunks = 4;                        // layer-2 chunks per wave: h2 <= 512
@@ -743,31 +787,30 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
 #endif
     float *sbias = reinterpret_cast<float *>(smem);                // b1 | b2 (zero padded to chunks) | b3 (32)
     char *sxb = reinterpret_cast<char *>(sbias + nb + 32);         // x operand [tile][part][lane] x 16 B
-    float *spart = reinterpret_cast<float *>(sxb + kXbBytes);      // [4 waves][kRowsX rows][33], shares LDS with the rings
+    float *spart = reinterpret_cast<float *>(sxb + kTilesX * kStageBytes);   // [4 waves][kRowsX rows][33], shares LDS with the rings
 
     // ---- the x operand: row 32 t + (lane & 31), inputs 8 (lane >> 5) .. + 7, split once, kept in LDS (every wave uses it)
     if (wave < kTilesX) {
         const int t = wave;
         const int e = e0 + 32 * t + (lane & 31), k0 = 8 * (lane >> 5);
         const float *xr = a.x + ((size_t)min(e, a.E - 1) * a.N + agent) * a.d_in;
-        unsigned h[8], m[8], l[8];
+        float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float xv = xr[min(k0 + j, a.d_in - 1)];          // clamped address, masked value: no branches
-            const float v = (e < a.E && k0 + j < a.d_in) ? xv : 0.0f;
-            h[j] = __float_as_uint(v);                             // (no relu on the inputs)
-            const float rem = v - __uint_as_float(h[j] & 0xffff0000u);
-            m[j] = __float_as_uint(rem);
-            l[j] = __float_as_uint(rem - __uint_as_float(m[j] & 0xffff0000u));
+            v[j] = (e < a.E && k0 + j < a.d_in) ? xv : 0.0f;
         }
-        u32x4 ph, pm, pl;
+        Parts<P> xp;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            ph[q] = upper_halves(h[2 * q + 1], h[2 * q]); pm[q] = upper_halves(m[2 * q + 1], m[2 * q]);
-            pl[q] = upper_halves(l[2 * q + 1], l[2 * q]);
+            unsigned d[P];
+            S::template split_pair<false>(v[2 * q], v[2 * q + 1], d);              // (no relu on the inputs)
+#pragma unroll
+            for (int p = 0; p < P; ++p) xp.p[p][q] = d[p];
         }
-        u32x4 *d = reinterpret_cast<u32x4 *>(sxb + t * 3072) + lane;
-        d[0] = ph; d[64] = pm; d[128] = pl;
+        u32x4 *dp = reinterpret_cast<u32x4 *>(sxb + t * kStageBytes) + lane;
+#pragma unroll
+        for (int p = 0; p < P; ++p) dp[64 * p] = xp.p[p];
     }
     uint32_t tval = 0, epval = 0;
     if (e0 + (tid >> 2) < a.E && a.fin.sample_kind != 0) {          // of the row this thread finishes (4 lanes per row)
@@ -795,8 +838,9 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
 #pragma unroll
     for (int t = 0; t < kTilesX; ++t) y[t] = f32x16{};
 
-    // ---- The weight fragments of this wave form ONE linear stream of 3 KiB stages (the three parts of one 32-feature
-    //      chunk x 16 k slots), laid out by the host in the order the matrix instructions want them (include/dronesim.h):
+    // ---- The weight fragments of this wave form ONE linear stream of stages (the P parts of one 32-feature chunk x
+    //      16 k slots, 1 KiB each), laid out by the host in the order the matrix instructions want them
+    //      (include/dronesim.h):
     //          W1(0), W2(0,0,*) | W1(1), W2(0,1,*), W2(1,0,*) | W1(2), W2(1,1,*), W2(2,0,*) | ... | W3(*)
     //      (W2(c1, ss, i): k-step 2 c1 + ss of this wave's i-th output chunk).  They travel global -> LDS by DMA
     //      (global_load_lds, 1 KiB per instruction) into a ring PRIVATE to the wave, requested kRingX stages before
@@ -804,114 +848,114 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
     //      the registers that stage has just finished with: no copies, no exposed LDS or L2 latency.  The ring needs no
     //      barrier (one wave writes and reads it); a read is ordered behind its DMA by the counted s_waitcnt vmcnt.
     //      The stream is padded by kRingX stages, so the producer never needs to know where it ends.
-    char *ring = reinterpret_cast<char *>(spart) + (size_t)wave * kRingX * 3072;
-    const bf16x8 *gp = a.ws + ((size_t)agent * 4 + wave) * a.stages * 192 + lane;
+    char *ring = reinterpret_cast<char *>(spart) + (size_t)wave * kRingX * kStageBytes;
+    const char *gp = a.ws + (((size_t)agent * 4 + wave) * a.stages * P * 64 + lane) * 16;
     int pslot = 0;
     auto request_part = [&](int p) {                               // 1 KiB of the stage kRingX ahead
-#ifdef DRONESIM_ABL_X3_ONEPART
-        if (p != 0) return;
-#endif
 #ifndef DRONESIM_ABL_X3_NODMA
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + (size_t)p * 64),
-                                         (__attribute__((address_space(3))) void *)(ring + pslot * 3072 + p * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + p * 1024),
+                                         (__attribute__((address_space(3))) void *)(ring + pslot * kStageBytes + p * 1024), 16, 0, 0);
 #endif
     };
     auto request_done = [&]() {
-#ifndef DRONESIM_ABL_X3_SAMEADDR
-        gp += 192;
-#endif
+        gp += kStageBytes;
         pslot = pslot + 1 == kRingX ? 0 : pslot + 1;
     };
-    auto request = [&]() { request_part(0); request_part(1); request_part(2); request_done(); };
-    bf16x8 wf[3];                                                  // the current stage's fragments (hi, mid, lo)
+    u32x4 wf[P];                                                   // the current stage's fragments, part 0 first
     int nslot = 1;                                                 // ring slot of the NEXT stage
-    // one stage: acc[t] += W * B[t], both operands in three parts = six products per tile, smallest first as far as the
-    // register hand-over allows (lo.hi, mid.mid, hi.lo, mid.hi, hi.mid, hi.hi); `job` gets one call per slot 1..8
-    auto stage = [&](f32x16 (&acc)[kTilesX], const Parts3 (&b)[kTilesX], auto &job) {
-        #ifdef DRONESIM_ABL_X3_ONEPART
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kRingX - 2) : "memory");
-#else
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (kRingX - 2)) : "memory");    // the NEXT stage has landed
-#endif
-        const char *np = ring + nslot * 3072 + lane * 16;
+    // one stage: acc[t] += W * B[t], the scheme's products on both tiles; slot s = the gap behind matrix instruction s:
+    // `job` is offered every slot, the ring reads and the DMA requests sit where the scheme puts them
+    auto stage = [&](f32x16 (&acc)[kTilesX], const Parts<P> (&b)[kTilesX], auto &job) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P * (kRingX - 2)) : "memory");    // the NEXT stage has landed
+        const char *np = ring + nslot * kStageBytes + lane * 16;
         X3_PIN();
-        X3_MFMA(acc[0], wf[2], b[0].hi);  X3_PIN();
-        X3_MFMA(acc[1], wf[2], b[1].hi);  X3_PIN();
-        X3_RING_READ(wf[2], np + 2048); job.template step<0>(); X3_PIN();
-        X3_MFMA(acc[0], wf[1], b[0].mid); X3_PIN(); job.template step<1>(); X3_PIN();
-        X3_MFMA(acc[1], wf[1], b[1].mid); X3_PIN(); request_part(0); job.template step<2>(); X3_PIN();
-        X3_MFMA(acc[0], wf[0], b[0].lo);  X3_PIN(); job.template step<3>(); X3_PIN();
-        X3_MFMA(acc[1], wf[0], b[1].lo);  X3_PIN(); job.template step<4>(); X3_PIN();
-        X3_MFMA(acc[0], wf[1], b[0].hi);  X3_PIN(); request_part(1); job.template step<5>(); X3_PIN();
-        X3_MFMA(acc[1], wf[1], b[1].hi);  X3_PIN();
-        X3_RING_READ(wf[1], np + 1024); job.template step<6>(); X3_PIN();
-        X3_MFMA(acc[0], wf[0], b[0].mid); X3_PIN(); job.template step<7>(); X3_PIN();
-        X3_MFMA(acc[1], wf[0], b[1].mid); X3_PIN();
-        request_part(2); request_done();                           // the stage kRingX ahead, into the slot this stage came from
-        X3_PIN();
-        X3_MFMA(acc[0], wf[0], b[0].hi);  X3_PIN();
-        X3_MFMA(acc[1], wf[0], b[1].hi);  X3_PIN();
-        X3_RING_READ(wf[0], np);
+        auto slot_work = [&](auto SLOT) {
+            constexpr int s = decltype(SLOT)::value, q = s >> 1;
+            acc[s & 1] = S::mfma(wf[S::w_part(q)], b[s & 1].p[S::b_part(q)], acc[s & 1]);
+            X3_PIN();
+            if constexpr (s & 1) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    if (S::last_use(p) == q) X3_RING_READ(wf[p], np + p * 1024);
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (S::request_slot(p) == s) { request_part(p); if (p == P - 1) request_done(); }
+            job.template slot<s>();
+            X3_PIN();
+        };
+        slot_work(std::integral_constant<int, 0>{}); slot_work(std::integral_constant<int, 1>{});
+        slot_work(std::integral_constant<int, 2>{}); slot_work(std::integral_constant<int, 3>{});
+        slot_work(std::integral_constant<int, 4>{}); slot_work(std::integral_constant<int, 5>{});
+        if constexpr (S::kProducts == 6) {
+            slot_work(std::integral_constant<int, 6>{}); slot_work(std::integral_constant<int, 7>{});
+            slot_work(std::integral_constant<int, 8>{}); slot_work(std::integral_constant<int, 9>{});
+            slot_work(std::integral_constant<int, 10>{}); slot_work(std::integral_constant<int, 11>{});
+        }
         nslot = nslot + 1 == kRingX ? 0 : nslot + 1;
         X3_PIN();
     };
 
     if (nmine > 0) {
 #pragma unroll 1
-        for (int j = 0; j < kRingX; ++j) request();
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * (kRingX - 1)) : "memory");
+        for (int j = 0; j < kRingX; ++j) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const bf16x8 *>(ring + p * 1024 + lane * 16);
+            for (int p = 0; p < P; ++p) request_part(p);
+            request_done();
+        }
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(P * (kRingX - 1)) : "memory");
+#pragma unroll
+        for (int p = 0; p < P; ++p) wf[p] = *reinterpret_cast<const u32x4 *>(ring + p * 1024 + lane * 16);
 
         NoJob nojob;
         f32x16 a1[kTilesX];
-        Parts3 hB0[kTilesX], hB1[kTilesX];                         // layer-2 operands of k-steps 2 c1 and 2 c1 + 1
+        Parts<P> hB0[kTilesX], hB1[kTilesX];                       // layer-2 operands of k-steps 2 c1 and 2 c1 + 1
         {                                                          // layer 1, chunk 0
-            Parts3 xB[kTilesX];
+            Parts<P> xB[kTilesX];
 #pragma unroll
-            for (int t = 0; t < kTilesX; ++t) { a1[t] = bias_tile(sbias, lane); xB[t] = parts_from_lds(sxb + t * 3072 + lane * 16); }
+            for (int t = 0; t < kTilesX; ++t) { a1[t] = bias_tile(sbias, lane); xB[t] = parts_from_lds<P>(sxb + t * kStageBytes + lane * 16); }
             stage(a1, xB, nojob);
 #pragma unroll
-            for (int t = 0; t < kTilesX; ++t) { SplitJob<0> j(a1[t], hB0[t]); j.all(); }
+            for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0> j(a1[t], hB0[t]); j.all(); }
         }
         for (int c1 = 0; c1 < NC1; ++c1) {
             // k-step 2 c1 of every chunk of mine; meanwhile the other half of a1 becomes hB1 (tile i in stage i)
 #pragma unroll
             for (int i = 0; i < kMaxChunks; ++i) {
                 if (i < nmine) {                                   // wave-uniform
-                    if (i < kTilesX) { SplitJobInStage<1> j(a1[i], hB1[i]); stage(acc2[i], hB0, j); }
+                    if (i < kTilesX) { SplitJobInStage<S, 1> j(a1[i], hB1[i]); stage(acc2[i], hB0, j); }
                     else stage(acc2[i], hB0, nojob);
                 }
             }
-            if (nmine < kTilesX) { SplitJob<1> j(a1[1], hB1[1]); j.all(); }
+            if (nmine < kTilesX) { SplitJob<S, 1> j(a1[1], hB1[1]); j.all(); }
             if (c1 + 1 < NC1) {                                    // layer 1 of the next chunk
-                Parts3 xB[kTilesX];
+                Parts<P> xB[kTilesX];
                 a1[0] = bias_tile(sbias + (c1 + 1) * 32, lane);
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) { a1[t] = a1[0]; xB[t] = parts_from_lds(sxb + t * 3072 + lane * 16); }
+                for (int t = 0; t < kTilesX; ++t) { a1[t] = a1[0]; xB[t] = parts_from_lds<P>(sxb + t * kStageBytes + lane * 16); }
                 stage(a1, xB, nojob);
             }
             // k-step 2 c1 + 1; meanwhile the first half of the next chunk becomes hB0 (stale and unused after the last chunk)
 #pragma unroll
             for (int i = 0; i < kMaxChunks; ++i) {
                 if (i < nmine) {
-                    if (i < kTilesX) { SplitJobInStage<0> j(a1[i], hB0[i]); stage(acc2[i], hB1, j); }
+                    if (i < kTilesX) { SplitJobInStage<S, 0> j(a1[i], hB0[i]); stage(acc2[i], hB1, j); }
                     else stage(acc2[i], hB1, nojob);
                 }
             }
-            if (nmine < kTilesX) { SplitJob<0> j(a1[1], hB0[1]); j.all(); }
+            if (nmine < kTilesX) { SplitJob<S, 0> j(a1[1], hB0[1]); j.all(); }
         }
 
         // ---- layer 3 from the finished layer-2 accumulators, same stream
 #pragma unroll
         for (int i = 0; i < kMaxChunks; ++i) {
             if (i < nmine) {
-                Parts3 pB[kTilesX];
+                Parts<P> pB[kTilesX];
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) { SplitJob<0> j(acc2[i][t], pB[t]); j.all(); }
+                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0> j(acc2[i][t], pB[t]); j.all(); }
                 stage(y, pB, nojob);
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) { SplitJob<1> j(acc2[i][t], pB[t]); j.all(); }
+                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 1> j(acc2[i][t], pB[t]); j.all(); }
                 stage(y, pB, nojob);
             }
         }
@@ -951,7 +995,6 @@ __global__ void __launch_bounds__(256, 2) mlp3_bf16x3_kernel(const float *x, int
         finish_quad(a.fin, yv, e, agent, part, tval, epval);
     }
 }
-#undef X3_MFMA
 #undef X3_PIN
 #undef X3_RING_READ
 
@@ -1068,37 +1111,59 @@ extern "C" int dronesim_mlp_bf16x3_stages(int h1, int h2)
     return nc1 * (1 + 2 * nm) + 2 * nm + kRingX;
 }
 
-extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
-                                           uint64_t seed, uint64_t counter, int64_t env_base,
-                                           const int32_t *t, const int32_t *episode, int E, void *stream)
+template <class S>
+int mlp_forward_split(const char *what, const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                      uint64_t seed, uint64_t counter, int64_t env_base, const int32_t *t, const int32_t *episode, int E,
+                      void *stream)
 {
-    if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16x3: NULL argument");
-    const int rc = check_mlp("bf16x3", m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
+    char msg[200];
+    if (!m || !x) { snprintf(msg, sizeof(msg), "dronesim_mlp_forward_%s: NULL argument", what); return dronesim_fail(DRONESIM_EINVAL, msg); }
+    const int rc = check_mlp(what, m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
     if (rc) return rc;
-    if (m->d_in > 16) return dronesim_fail(DRONESIM_EUNSUPPORTED, "bf16x3 path: d_in <= 16");
-    if (!m->w1p || !m->b1 || !m->b2 || !m->b3)
-        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16x3: NULL weight array");
+    if (m->d_in > 16) { snprintf(msg, sizeof(msg), "%s path: d_in <= 16", what); return dronesim_fail(DRONESIM_EUNSUPPORTED, msg); }
+    if (!m->w1p || !m->b1 || !m->b2 || !m->b3) {
+        snprintf(msg, sizeof(msg), "dronesim_mlp_forward_%s: NULL weight array", what);
+        return dronesim_fail(DRONESIM_EINVAL, msg);
+    }
     if (E == 0) return DRONESIM_OK;
     MArgsX a{};
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2;
     a.nc1 = (m->h1 + 31) / 32; a.nc2 = (m->h2 + 31) / 32;
     a.stages = dronesim_mlp_bf16x3_stages(m->h1, m->h2);
-    if (m->reserved != a.stages)
-        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16x3: DroneMlpBf16.reserved must hold "
-                                              "dronesim_mlp_bf16x3_stages(h1, h2), the stages per stream of w1p");
+    if (m->reserved != a.stages) {
+        snprintf(msg, sizeof(msg), "dronesim_mlp_forward_%s: DroneMlpBf16.reserved must hold dronesim_mlp_bf16x3_stages(h1, h2), "
+                                   "the stages per stream of w1p", what);
+        return dronesim_fail(DRONESIM_EINVAL, msg);
+    }
     a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
-    a.ws = reinterpret_cast<const bf16x8 *>(m->w1p);
+    a.ws = reinterpret_cast<const char *>(m->w1p);
 #if defined(DRONESIM_TRACE)
     a.trace = g_policy_trace;
 #endif
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
-    const size_t part_bytes = sizeof(float) * 4 * kRowsX * 33, ring_bytes = (size_t)4 * kRingX * 3072;   // the two share LDS
-    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32) + kXbBytes + (part_bytes > ring_bytes ? part_bytes : ring_bytes);
-    hipLaunchKernelGGL(mlp3_bf16x3_kernel, dim3(((E + kRowsX - 1) / kRowsX) * m->N), dim3(256), lds,
+    constexpr size_t stage_bytes = S::kParts * 1024;
+    const size_t part_bytes = sizeof(float) * 4 * kRowsX * 33, ring_bytes = (size_t)4 * kRingX * stage_bytes;   // the two share LDS
+    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32) + kTilesX * stage_bytes +
+                       (part_bytes > ring_bytes ? part_bytes : ring_bytes);
+    hipLaunchKernelGGL(mlp3_split_kernel<S>, dim3(((E + kRowsX - 1) / kRowsX) * m->N), dim3(256), lds,
                        static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
+}
+
+extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                                           uint64_t seed, uint64_t counter, int64_t env_base,
+                                           const int32_t *t, const int32_t *episode, int E, void *stream)
+{
+    return mlp_forward_split<SchemeBf16x3>("bf16x3", m, x, out, act, act_idx, seed, counter, env_base, t, episode, E, stream);
+}
+
+extern "C" int dronesim_mlp_forward_f16x2(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                                          uint64_t seed, uint64_t counter, int64_t env_base,
+                                          const int32_t *t, const int32_t *episode, int E, void *stream)
+{
+    return mlp_forward_split<SchemeF16x2>("f16x2", m, x, out, act, act_idx, seed, counter, env_base, t, episode, E, stream);
 }
 
 extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,

@@ -27,7 +27,7 @@ def _wt(layer):
     return layer.weight.detach().t().contiguous().float(), layer.bias.detach().contiguous().float()
 
 
-def pack_bf16_fragments(w, ksteps, nchunks, k_order="linear"):
+def pack_bf16_fragments(w, ksteps, nchunks, k_order="linear", dtype=None):
     """[N, K, F] float weights -> matrix-core fragments [N, nchunks, ksteps, 64, 8] in bf16, the layout
     `dronesim_mlp_forward_bf16` reads with one 16-byte load per lane:
         frag[a, c, s, l, j] = w[a, kmap(s, l >> 5, j), 32 c + (l & 31)]      (zero beyond K / F)
@@ -45,7 +45,7 @@ def pack_bf16_fragments(w, ksteps, nchunks, k_order="linear"):
         frag = pad.view(n, ksteps, 2, 2, 4, nchunks, 32).permute(0, 5, 1, 3, 6, 2, 4)
     else:
         raise ValueError("k_order must be 'linear' or 'accumulator'")
-    return frag.reshape(n, nchunks, ksteps, 64, 8).to(torch.bfloat16).contiguous()
+    return frag.reshape(n, nchunks, ksteps, 64, 8).to(dtype or torch.bfloat16).contiguous()
 
 
 def split3_bf16(w):
@@ -60,12 +60,30 @@ def split3_bf16(w):
     return hi, mid, lo
 
 
-def pack_bf16x3_fragments(w, ksteps, nchunks, k_order):
-    """[N, K, F] float32 weights -> ``[N, nchunks, ksteps, 3, 64, 8]`` bf16: the hi / mid / lo fragments of
-    `dronesim_mlp_forward_bf16x3` side by side per (agent, chunk, k-step)."""
+def split2_f16(w):
+    """float32 tensor -> (hi, lo) with hi = float16(w), lo = float16(w - hi): w == hi + lo to 2^-22 relative
+    (float32 tensors holding float16-representable values; |w| must stay below 65504)."""
     import torch
-    parts = [pack_bf16_fragments(p, ksteps, nchunks, k_order) for p in split3_bf16(w)]
+    w = w.float().contiguous()
+    hi = w.to(torch.float16).float()
+    return hi, (w - hi).to(torch.float16).float()
+
+
+def pack_split_fragments(w, ksteps, nchunks, k_order, scheme="bf16x3"):
+    """[N, K, F] float32 weights -> ``[N, nchunks, ksteps, P, 64, 8]``: the P parts' fragments of the split
+    schemes side by side per (agent, chunk, k-step): bf16 hi / mid / lo ("bf16x3") or float16 hi / lo ("f16x2")."""
+    import torch
+    if scheme == "bf16x3":
+        parts = [pack_bf16_fragments(p, ksteps, nchunks, k_order) for p in split3_bf16(w)]
+    elif scheme == "f16x2":
+        parts = [pack_bf16_fragments(p, ksteps, nchunks, k_order, dtype=torch.float16) for p in split2_f16(w)]
+    else:
+        raise ValueError("scheme must be 'bf16x3' or 'f16x2'")
     return torch.stack(parts, dim=3).contiguous()
+
+
+def pack_bf16x3_fragments(w, ksteps, nchunks, k_order):
+    return pack_split_fragments(w, ksteps, nchunks, k_order, "bf16x3")
 
 
 def stack_reference_modules(modules, kind=None):
@@ -98,17 +116,18 @@ def stack_reference_modules(modules, kind=None):
     return st(w1), st(b1), st(w2), st(b2), st(w3), st(b3), OUT_TANH_SIGMOID, SAMPLE_GAUSSIAN
 
 
-def pack_bf16x3_streams(w1, w2, w3, stages):
-    """The weight image of `dronesim_mlp_forward_bf16x3` (include/dronesim.h): per (agent, wave) one stream of
-    `stages` 3 KiB stages -- hi | mid | lo fragments of one (chunk, k-step) -- in the kernel's consumption order.
-    Returns ``[N, 4, stages, 3, 64, 8]`` bf16."""
+def pack_split_streams(w1, w2, w3, stages, scheme="bf16x3"):
+    """The weight image of `dronesim_mlp_forward_bf16x3` / `_f16x2` (include/dronesim.h): per (agent, wave) one
+    stream of `stages` stages -- the P parts' fragments of one (chunk, k-step), 1 KiB each -- in the kernel's
+    consumption order.  Returns ``[N, 4, stages, P, 64, 8]`` bf16 (P = 3) or float16 (P = 2)."""
     import torch
     n, _, h1 = w1.shape
     h2 = w2.shape[2]
     nc1, nc2 = (h1 + 31) // 32, (h2 + 31) // 32
-    f1 = pack_bf16x3_fragments(w1, 1, nc1, "linear").reshape(n, nc1, 3, 64, 8)                    # [c1]
-    f2 = pack_bf16x3_fragments(w2, 2 * nc1, nc2, "accumulator").reshape(n, nc2 * 2 * nc1, 3, 64, 8)  # [c2 * KS2 + s]
-    f3 = pack_bf16x3_fragments(w3, 2 * nc2, 1, "accumulator").reshape(n, 2 * nc2, 3, 64, 8)       # [s]
+    P = 3 if scheme == "bf16x3" else 2
+    f1 = pack_split_fragments(w1, 1, nc1, "linear", scheme).reshape(n, nc1, P, 64, 8)                      # [c1]
+    f2 = pack_split_fragments(w2, 2 * nc1, nc2, "accumulator", scheme).reshape(n, nc2 * 2 * nc1, P, 64, 8)  # [c2 * KS2 + s]
+    f3 = pack_split_fragments(w3, 2 * nc2, 1, "accumulator", scheme).reshape(n, 2 * nc2, P, 64, 8)         # [s]
     table = torch.cat([f1, f2, f3, torch.zeros_like(f1[:, :1])], dim=1)
     o2, o3, zero = nc1, nc1 + nc2 * 2 * nc1, nc1 + nc2 * 2 * nc1 + 2 * nc2
     streams = []
@@ -129,13 +148,18 @@ def pack_bf16x3_streams(w1, w2, w3, stages):
     return table[:, idx].contiguous()
 
 
+def pack_bf16x3_streams(w1, w2, w3, stages):
+    return pack_split_streams(w1, w2, w3, stages, "bf16x3")
+
+
 class BatchedMLP:
     def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0, precision="f32"):
         """w1 [N,d_in,h1], b1 [N,h1], w2 [N,h1,h2], b2 [N,h2], w3 [N,h2,nout], b3 [N,nout] (float32).
-        ``precision="f32"`` (default) is exact float32 on the matrix cores; ``"bf16x3"`` gives float32-accurate
-        results (same 1e-5 bar) from three-part bf16 splits of weights and activations on the bf16 matrix
-        instructions, ~2.5x faster; ``"bf16"`` runs weights and activations in plain bfloat16 with float32
-        accumulation (~1e-2 relative agreement, fastest)."""
+        ``precision="f32"`` (default) is exact float32 on the matrix cores; ``"bf16x3"`` and ``"f16x2"`` give
+        float32-accurate results (same 1e-5 bar) from three-part bfloat16 / two-part float16 splits of weights and
+        activations on the 16-bit matrix instructions (six / three partial products); f16x2 is the faster one and
+        needs every weight, input and hidden activation below 65504 in magnitude; ``"bf16"`` runs weights and
+        activations in plain bfloat16 with float32 accumulation (~1e-2 relative agreement, fastest)."""
         import torch
         from . import _native
         self._torch, self._native = torch, _native
@@ -170,11 +194,11 @@ class BatchedMLP:
             mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), self._w2p.data_ptr(), self._w3p.data_ptr()
             mb.b1, mb.b2, mb.b3 = self.b1.data_ptr(), self.b2.data_ptr(), self.b3.data_ptr()
             self._m = mb
-        elif precision == "bf16x3":
+        elif precision in ("bf16x3", "f16x2"):
             if self.d_in > 16:
-                raise ValueError("the bf16x3 path supports d_in <= 16")
+                raise ValueError(f"the {precision} path supports d_in <= 16")
             stages = int(self._lib.dronesim_mlp_bf16x3_stages(self.h1, self.h2))
-            self._w1p = pack_bf16x3_streams(self.w1, self.w2, self.w3, stages)
+            self._w1p = pack_split_streams(self.w1, self.w2, self.w3, stages, precision)
             mb = _native.DroneMlpBf16()
             mb.N, mb.d_in, mb.h1, mb.h2, mb.nout = self.n_agents, self.d_in, self.h1, self.h2, self.nout
             mb.out_kind, mb.sample_kind, mb.reserved = self.out_kind, self.sample_kind, stages
@@ -182,7 +206,7 @@ class BatchedMLP:
             mb.b1, mb.b2, mb.b3 = self.b1.data_ptr(), self.b2.data_ptr(), self.b3.data_ptr()
             self._m = mb
         elif precision != "f32":
-            raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16'")
+            raise ValueError("precision must be 'f32', 'f16x2', 'bf16x3' or 'bf16'")
 
     # ------------------------------------------------------------------ constructors
     @classmethod
@@ -225,6 +249,7 @@ class BatchedMLP:
             if self.sample_kind == SAMPLE_CATEGORICAL:
                 idx = torch.empty(E, self.n_agents, dtype=torch.int32, device=self.device)
         entry = {"bf16": self._lib.dronesim_mlp_forward_bf16, "bf16x3": self._lib.dronesim_mlp_forward_bf16x3,
+                 "f16x2": self._lib.dronesim_mlp_forward_f16x2,
                  "f32": self._lib.dronesim_mlp_forward}[self.precision]
         with torch.cuda.device(self.device):
             rc = entry(C.byref(m), z.data_ptr(), None if out is None else out.data_ptr(),

@@ -673,21 +673,22 @@ def test_batched_policy_large_batch_and_sampling_statistics(torch):
     H.assert_close(host(crit.forward(x.cuda())), ref(x, wc, lambda y: y), "critic 200x200x1")
 
 
-def test_batched_policy_bf16x3_holds_the_float32_bar(torch):
-    """precision="bf16x3": three-part bf16 splits of weights and activations, six matrix instructions per product --
-    the SAME 1e-5 bar as the exact-float32 kernel: on the reference's own networks (policies.npz) and on random
-    networks of all three shapes vs float64, ragged E, hidden widths that are not multiples of 32; sampling streams
-    identical to the float32 path (same Philox keys)."""
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
+def test_batched_policy_split_precisions_hold_the_float32_bar(torch, prec):
+    """precision="bf16x3" (three-part bf16 splits of weights and activations, six matrix instructions per product) and
+    "f16x2" (two-part float16 splits, three per product): the SAME 1e-5 bar as the exact-float32 kernel: on the
+    reference's own networks (policies.npz) and on random networks of all three shapes vs float64, ragged E, hidden
+    widths that are not multiples of 32; sampling streams identical to the float32 path (same Philox keys)."""
     from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
     fx = H.load("policies.npz")
     x = torch.tensor(fx["x"], dtype=torch.float32, device="cuda:0")
-    kw = dict(precision="bf16x3")
+    kw = dict(precision=prec)
     soft = BatchedMLP.from_discrete_softmax(_modules(fx, "soft", ["input_layer", "hidden_layer1", "out_1"]), **kw)
-    H.assert_close(host(soft.forward(x)), fx["soft_out"], "softmax probs (bf16x3)")
+    H.assert_close(host(soft.forward(x)), fx["soft_out"], f"softmax probs ({prec})")
     norm = BatchedMLP.from_normal_actor(_modules(fx, "norm", ["input_layer", "hidden_layer1", "hidden_layer2", "out_1", "out_2"]), **kw)
-    H.assert_close(host(norm.forward(x)), fx["norm_out"], "mu, sigma^2 (bf16x3)")
+    H.assert_close(host(norm.forward(x)), fx["norm_out"], f"mu, sigma^2 ({prec})")
     crit = BatchedMLP.from_critic(_modules(fx, "crit", ["input_layer", "hidden_layer1", "output_layer"]), **kw)
-    H.assert_close(host(crit.forward(x)), fx["crit_out"], "critic value (bf16x3)")
+    H.assert_close(host(crit.forward(x)), fx["crit_out"], f"critic value ({prec})")
     g = torch.Generator().manual_seed(31)
     N, E, d = 5, 333, 6
 
@@ -705,17 +706,17 @@ def test_batched_policy_bf16x3_holds_the_float32_bar(torch):
             (77, 130, 9, 1, 1, lambda y: torch.softmax(y, -1)),
             (512, 512, 32, 0, 0, lambda y: y)]:
         w = (r(N, d, h1) * 0.4, r(N, h1) * 0.4, r(N, h1, h2) * 0.08, r(N, h2) * 0.4, r(N, h2, nout) * 0.08, r(N, nout) * 0.4)
-        x3 = BatchedMLP(*w, out_kind=ok, sample_kind=sk, precision="bf16x3", seed=3)
+        x3 = BatchedMLP(*w, out_kind=ok, sample_kind=sk, precision=prec, seed=3)
         f32 = BatchedMLP(*w, out_kind=ok, sample_kind=sk, precision="f32", seed=3)
         y3 = host(x3.forward(xr.cuda()))
-        H.assert_close(y3, ref(xr, w, act), f"bf16x3 vs float64 {h1}x{h2}x{nout}")
-        H.assert_close(y3, host(f32.forward(xr.cuda())), f"bf16x3 vs f32 kernel {h1}")
+        H.assert_close(y3, ref(xr, w, act), f"{prec} vs float64 {h1}x{h2}x{nout}")
+        H.assert_close(y3, host(f32.forward(xr.cuda())), f"{prec} vs f32 kernel {h1}")
         if sk == 1:
             a3, i3 = x3.sample_action(xr.cuda()); a1, i1 = f32.sample_action(xr.cuda())
             assert float((i3 == i1).float().mean()) > 0.999                  # same uniforms, cdfs equal to ~1e-7
         if sk == 2:
             a3, _ = x3.sample_action(xr.cuda()); a1, _ = f32.sample_action(xr.cuda())
-            H.assert_close(host(a3), host(a1), "Gaussian samples bf16x3 vs f32", rtol=1e-4, atol=1e-4)
+            H.assert_close(host(a3), host(a1), f"Gaussian samples {prec} vs f32", rtol=1e-4, atol=1e-4)
 
 
 def test_policy_rollout_loop_under_graph_replay(torch):

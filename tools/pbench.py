@@ -45,7 +45,7 @@ if __name__ == "__main__":
     for spec in (sys.argv[1:] or ["c3", "c2", "c5"]):
         N, E, G, delta = PRESETS[spec]
         env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1)
-        for kind, prec in [(k, p) for p in (os.environ.get("PB_PREC", "f32,bf16x3,bf16").split(",")) for k in os.environ.get("PB_KINDS", "softmax16,gaussian,critic").split(",")]:
+        for kind, prec in [(k, p) for p in (os.environ.get("PB_PREC", "f32,bf16x3,f16x2,bf16").split(",")) for k in os.environ.get("PB_KINDS", "softmax16,gaussian,critic").split(",")]:
             pol, (h1, h2, nout) = rnd_policy(kind, N, 6, env.device, prec)
             z = env.z
             flops = 2.0 * E * N * (6 * h1 + h1 * h2 + h2 * nout)
