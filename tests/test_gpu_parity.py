@@ -228,8 +228,10 @@ def test_step_matches_oracle(torch, cfg):
     np.testing.assert_array_equal(host(nbc), cnt)
 
 
-def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch):
-    """BASELINE configs[4] as it is stated: n = 256 agents x 512 envs (one GPU's shard of 4096), Delta = 2.5, G = 256,
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
+def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch, prec):
+    """(exact-float32 policy kernel, and the float16-split one that the C5 bench line is quoted with.)
+    BASELINE configs[4] as it is stated: n = 256 agents x 512 envs (one GPU's shard of 4096), Delta = 2.5, G = 256,
     actions from a continuous Gaussian policy -- the batched per-agent NormalActorNN (6 -> 400 -> (200 | 200) ->
     tanh mu[2] | sigmoid var[2], utils.py:55-117) evaluated on the env's own observation every step.
     Policy outputs vs a float64 torch evaluation of the SAME two-head networks (1e-5 bar); the sampled actions are
@@ -248,7 +250,7 @@ def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch):
         m.input_layer, m.hidden_layer1, m.hidden_layer2 = lin(6, 400, 0.08), lin(400, 200, 0.08), lin(400, 200, 0.08)
         m.out_1, m.out_2 = lin(200, 2, 0.15), lin(200, 2, 0.15)
         mods.append(m)
-    pol = BatchedMLP.from_normal_actor(mods, seed=9)
+    pol = BatchedMLP.from_normal_actor(mods, seed=9, precision=prec)
     assert (pol.h1, pol.h2, pol.nout) == (400, 400, 4)
     W = lambda name: torch.stack([getattr(m, name).weight.double() for m in mods])          # [N, out, in]
     B = lambda name: torch.stack([getattr(m, name).bias.double() for m in mods])

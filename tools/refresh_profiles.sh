@@ -16,6 +16,7 @@ $T python bench.py --steps 2000 --warmup 200 --no-cpu-baseline --no-episode-laye
 $T python bench.py --workload c5 --steps 1000 --warmup 100 --no-cpu-baseline > $OUT/${TAG}_c5_bench.json 2>> $OUT/${TAG}_c3_bench.err
 $T python bench.py --workload c5 --policy gaussian --steps 400 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_c5_gaussian_f32_bench.json 2>> $OUT/${TAG}_c3_bench.err
 $T python bench.py --workload c5 --policy gaussian --policy-precision bf16x3 --steps 400 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_c5_gaussian_bf16x3_bench.json 2>> $OUT/${TAG}_c3_bench.err
+$T python bench.py --workload c5 --policy gaussian --policy-precision f16x2 --steps 400 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_c5_gaussian_f16x2_bench.json 2>> $OUT/${TAG}_c3_bench.err
 $T python bench.py --workload c5 --policy gaussian --policy-precision bf16 --steps 400 --warmup 20 --no-cpu-baseline > $OUT/${TAG}_c5_gaussian_bf16_bench.json 2>> $OUT/${TAG}_c3_bench.err
 $T python bench.py --workload c2 --steps 2000 --warmup 200 --no-cpu-baseline > $OUT/${TAG}_c2_bench.json 2>> $OUT/${TAG}_c3_bench.err
 cd /tmp
@@ -29,8 +30,8 @@ prof() {   # name, command...
 cp $(find $OUT/prof_c3_bench -name '*domain_stats.csv' | head -1) $OUT/${TAG}_c3_bench_domain_stats.csv 2>/dev/null
 (cd $ROOT && prof c3_kbench python tools/kbench.py c3)
 (cd $ROOT && prof rollout python tools/rbench.py c3 c5)
-(cd $ROOT && PB_PREC=f32,bf16x3,bf16 prof c3_policy python tools/pbench.py c3)
-(cd $ROOT && PB_PREC=f32,bf16x3,bf16 prof c5_policy python tools/pbench.py c5)
+(cd $ROOT && PB_PREC=f32,bf16x3,f16x2,bf16 prof c3_policy python tools/pbench.py c3)
+(cd $ROOT && PB_PREC=f32,bf16x3,f16x2,bf16 prof c5_policy python tools/pbench.py c5)
 (cd $ROOT && prof fbench python tools/fbench.py)
 (cd $ROOT && prof reset_probe python tools/reset_probe.py c3)
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -41,5 +42,5 @@ done
 (cd $ROOT/tools && python pmc_parse.py $OUT/pmc_$TAG c3 > $OUT/${TAG}_c3_pmc_traffic.json)
 tail -5 $OUT/${TAG}_c3_pmc_traffic.json
 (cd $ROOT && bash tools/sq_counters.sh $TAG c3 > $OUT/${TAG}_sq.log 2>&1)
-(cd $ROOT && $T python tools/kbench.py c3 c2 c5 256x4096:256:2.5 c3x8 > $OUT/${TAG}_kbench.log 2>&1; PB_PREC=f32,bf16x3,bf16 $T python tools/pbench.py c3 c5 > $OUT/${TAG}_pbench.log 2>&1; $T python tools/rbench.py c3 c5 > $OUT/${TAG}_rbench.log 2>&1; $T python tools/epibench.py 5 c3 > $OUT/${TAG}_epibench.log 2>&1; $T python tools/reset_probe.py c3 c5 c2 > $OUT/${TAG}_reset_probe.log 2>&1; $T python tools/fbench.py > $OUT/${TAG}_fbench.log 2>&1)
+(cd $ROOT && $T python tools/kbench.py c3 c2 c5 256x4096:256:2.5 c3x8 > $OUT/${TAG}_kbench.log 2>&1; PB_PREC=f32,bf16x3,f16x2,bf16 $T python tools/pbench.py c3 c5 > $OUT/${TAG}_pbench.log 2>&1; $T python tools/rbench.py c3 c5 > $OUT/${TAG}_rbench.log 2>&1; $T python tools/epibench.py 5 c3 > $OUT/${TAG}_epibench.log 2>&1; $T python tools/reset_probe.py c3 c5 c2 > $OUT/${TAG}_reset_probe.log 2>&1; $T python tools/fbench.py > $OUT/${TAG}_fbench.log 2>&1)
 cat $OUT/${TAG}_kbench.log
