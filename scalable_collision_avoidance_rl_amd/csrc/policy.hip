@@ -636,7 +636,6 @@ struct MArgsX {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 template <int P> struct Parts { u32x4 p[P]; };     // the P parts of a lane's 8 k-slots (two 16-bit values per dword, low half first)
 
 __device__ __forceinline__ unsigned upper_halves(unsigned odd, unsigned even)      // -> {even.hi16 (low), odd.hi16 (high)}
@@ -682,8 +681,11 @@ struct SchemeF16x2 {                                   // v = hi + lo to 2^-22 (
     template <bool RELU> __device__ static __forceinline__ void split_pair(float v0, float v1, unsigned (&d)[2])
     {
         if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
-        const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);                   // any rounding will do: v - hi is exact
-        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h[0], v1 - (float)h[1]);
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+        const f32x2v v = {v0, v1};                                             // round to nearest twice (v_cvt_pk_f16_f32):
+        const f16x2v h = __builtin_convertvector(v, f16x2v);                   // |v - hi| <= 2^-11 |v|, v - hi exact in float32,
+        const f16x2v l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2v), f16x2v);   // |v - hi - lo| <= 2^-22 |v|
         d[0] = __builtin_bit_cast(unsigned, h); d[1] = __builtin_bit_cast(unsigned, l);
     }
 };

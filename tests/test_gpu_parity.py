@@ -706,6 +706,8 @@ def test_batched_policy_split_precisions_hold_the_float32_bar(torch, prec):
             (400, 400, 4, 2, 2, lambda y: torch.cat([torch.tanh(y[..., :2]), torch.sigmoid(y[..., 2:])], -1)),
             (200, 200, 1, 0, 0, lambda y: y),
             (77, 130, 9, 1, 1, lambda y: torch.softmax(y, -1)),
+            (40, 72, 4, 0, 0, lambda y: y),                       # fewer layer-2 chunks than waves
+            (20, 20, 1, 0, 0, lambda y: y),
             (512, 512, 32, 0, 0, lambda y: y)]:
         w = (r(N, d, h1) * 0.4, r(N, h1) * 0.4, r(N, h1, h2) * 0.08, r(N, h2) * 0.4, r(N, h2, nout) * 0.08, r(N, nout) * 0.4)
         x3 = BatchedMLP(*w, out_kind=ok, sample_kind=sk, precision=prec, seed=3)

@@ -125,6 +125,51 @@ def test_argument_errors_are_reported_without_a_gpu():
         _native.check(_native.EINVAL, "unit-test")
 
 
+def test_split_policy_boundary_without_a_gpu():
+    """dronesim_mlp_forward_bf16x3 / _f16x2: argument errors are reported before any HIP call; the stage count of the
+    weight streams; `pack_split_streams` lays the fragments out in the order include/dronesim.h states, and the parts
+    of both schemes add up to the float32 weights (exactly for bf16x3, to 2^-22 for f16x2)."""
+    import torch
+    from scalable_collision_avoidance_rl_amd import policies as P
+    lib = _native.lib()
+    nul = None
+    for fn in (lib.dronesim_mlp_forward_bf16x3, lib.dronesim_mlp_forward_f16x2):
+        assert fn(None, nul, nul, nul, nul, 0, 0, 0, nul, nul, 4, nul) == _native.EINVAL
+        m = _native.DroneMlpBf16()
+        m.N, m.d_in, m.h1, m.h2, m.nout, m.out_kind, m.sample_kind = 2, 6, 40, 72, 4, 0, 0
+        one = C.c_void_p(16)                                      # any non-NULL address: validation never dereferences
+        m.w1p, m.b1, m.b2, m.b3 = one, one, one, one
+        m.reserved = 0
+        assert fn(C.byref(m), one, nul, nul, nul, 0, 0, 0, nul, nul, 4, nul) == _native.EINVAL
+        assert b"stages" in lib.dronesim_last_error()
+        m.reserved = lib.dronesim_mlp_bf16x3_stages(40, 72)
+        assert fn(C.byref(m), one, nul, nul, nul, 0, 0, 0, nul, nul, 0, nul) == _native.OK       # E = 0: nothing to do
+        m.d_in = 17
+        assert fn(C.byref(m), one, nul, nul, nul, 0, 0, 0, nul, nul, 4, nul) == _native.EUNSUPPORTED
+    # h1 = 40 -> 2 chunks, h2 = 72 -> 3 chunks: waves 0..2 own one chunk, wave 3 none; wave 0's stream is
+    # W1(0) W2(0,0) W1(1) W2(0,1) W2(1,0) W2(1,1) W3(0,0) W3(0,1) + 4 stages of padding
+    stages = lib.dronesim_mlp_bf16x3_stages(40, 72)
+    assert stages == 2 * (1 + 2 * 1) + 2 * 1 + 4
+    g = torch.Generator().manual_seed(5)
+    w1, w2, w3 = (torch.rand(*s, generator=g) * 2 - 1 for s in ((2, 6, 40), (2, 40, 72), (2, 72, 4)))
+    for scheme, nparts, dtype in (("bf16x3", 3, torch.bfloat16), ("f16x2", 2, torch.float16)):
+        st = P.pack_split_streams(w1, w2, w3, stages, scheme)
+        assert tuple(st.shape) == (2, 4, stages, nparts, 64, 8) and st.dtype == dtype
+        f1 = P.pack_split_fragments(w1, 1, 2, "linear", scheme)           # [N, c1, 1, P, 64, 8]
+        f2 = P.pack_split_fragments(w2, 4, 3, "accumulator", scheme)      # [N, c2, s, P, 64, 8]
+        f3 = P.pack_split_fragments(w3, 6, 1, "accumulator", scheme)      # [N, 1, s, P, 64, 8]
+        for w in range(3):
+            want = [f1[:, 0, 0], f2[:, w, 0], f1[:, 1, 0], f2[:, w, 1], f2[:, w, 2], f2[:, w, 3], f3[:, 0, 2 * w], f3[:, 0, 2 * w + 1]]
+            for j, fr in enumerate(want):
+                assert torch.equal(st[:, w, j], fr), (scheme, w, j)
+            assert not st[:, w, len(want):].float().abs().sum()           # zero padding
+        assert torch.equal(st[:, 3, 1], f1[:, 1, 0]) and not st[:, 3, 2:].float().abs().sum()   # wave 3 owns no chunk (the kernel skips it)
+        total = f2.float().sum(dim=3)                                      # parts add up to the weights, fragment by fragment
+        ref = P.pack_bf16_fragments(w2, 4, 3, "accumulator", dtype=torch.float32)
+        err = (total - ref).abs().max().item()
+        assert err == 0.0 if scheme == "bf16x3" else err < 2.0 ** -21
+
+
 def test_env_refuses_to_run_without_gpu():
     import torch
     if torch.cuda.is_available():
