@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DRONESIM_VERSION 200           /* 0.2.0 */
+#define DRONESIM_VERSION 201           /* 0.2.1 */
 #define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
 #define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
 
@@ -78,6 +78,11 @@ typedef struct DroneParams {
     const float *d_hat;     /* [N]    */
     const float *delta;     /* [N]    */
     const float *radius;    /* [N]    */
+    /* optional (NULL = zeros): the part of the float64 goal ring that float32 drops, xF_lo = (float)(xF64 - (double)xF),
+       [N][2].  The kernels form x - xF as (x - xF) - xF_lo: the first difference is exact near the goal, so the offset,
+       the arrival test (:251) and the ghost direction (:383-386) keep float32 RELATIVE accuracy there instead of an
+       absolute ulp32(G) -- without it a ghost row of an agent 0.04 from its goal is 2e-5 off the reference's at G = 31. */
+    const float *xF_lo;
 } DroneParams;
 
 /* drones.step(actions)                                   drone_env.py:214-258

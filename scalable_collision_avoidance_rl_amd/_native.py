@@ -37,7 +37,7 @@ class DroneParams(C.Structure):
                 ("d_hat_min", C.c_float), ("d_hat_max", C.c_float), ("delta_min", C.c_float), ("delta_max", C.c_float),
                 ("radius_min", C.c_float), ("radius_max", C.c_float),
                 ("xF", C.c_void_p), ("d_hat", C.c_void_p), ("delta", C.c_void_p),
-                ("radius", C.c_void_p)]
+                ("radius", C.c_void_p), ("xF_lo", C.c_void_p)]
 
 
 class DroneEpisodeAcc(C.Structure):

@@ -79,6 +79,7 @@ struct KArgs {
     int P, epb;                     // envs per wave (0 when N > 64), envs per workgroup
     float dt, q, b, done_radius, ghost_factor, radius_max, reach_max;
     const float *xF, *d_hat, *delta, *radius;
+    const float *xF_lo;             // low-order part of the goal ring (xF + xF_lo = the float64 goal to 2^-48), or NULL
     float *pos, *vel;
     int *t;
     const float *act;
@@ -397,7 +398,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     uint32_t epi = 0u;
     uint32_t rnd[4] = {0u, 0u, 0u, 0u};                      // rand_act: the Philox block of steps (t & ~1, t | 1)
     const uint32_t gid = a.gid_base + (uint32_t)env;         // global env id (independent of the sharding)
-    float xFx = 0.f, xFy = 0.f, dhat = 1.f, delta_i = 0.f, li = 0.f;
+    float xFx = 0.f, xFy = 0.f, xLx = 0.f, xLy = 0.f, dhat = 1.f, delta_i = 0.f, li = 0.f;
     // base addresses of the first loads, computed on the scalar unit before the branch
     const float2 *pos_in = reinterpret_cast<const float2 *>(a.pos) + wga0;
     const float2 *vel_in = reinterpret_cast<const float2 *>(MODE == kObserve ? a.vel : a.act) + wga0;
@@ -437,6 +438,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #endif
         }
         const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
+        if (a.xF_lo) {                                        // wave-uniform
+            const float2 gl = reinterpret_cast<const float2 *>(a.xF_lo)[(unsigned)agent];
+            xLx = gl.x; xLy = gl.y;
+        }
         if (a.uniform) {
             dhat = a.dhat_u; delta_i = a.delta_u; li = a.radius_u;
         } else {
@@ -806,8 +811,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         if (valid) {
             TRACE_MARK(3);
             // rewards (:276, :287-288)
-            const float gx = xFx - xi, gy = xFy - yi;
-            const float err2 = fmaf(gy, gy, gx * gx);
+            // x - xF with the goal in two float32 parts: the first difference is exact near the goal (Sterbenz), so the
+            // offset keeps float32 RELATIVE accuracy where the ghost direction and the arrival test are sensitive to it
+            const float zx = (xi - xFx) - xLx, zy = (yi - xFy) - xLy;         // :357
+            const float err2 = fmaf(zy, zy, zx * zx);
             const float to_goal = a.q * err2;
             r_out = -nan_to_num_f32(fmaf(a.b, s_msk, to_goal));
             tr_out = -nan_to_num_f32(fmaf(a.b, s_all, to_goal));
@@ -819,7 +826,6 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             }
 
             // localized state rows + neighbour list (:344-397)
-            const float zx = xi - xFx, zy = yi - xFy;                         // :357
             const float gsc = __builtin_amdgcn_rsqf(err2) * delta_i * a.ghost_factor;
             const float ghx = zx * gsc, ghy = zy * gsc;                       // :386 (NaN when on the goal)
             zrx[0] = zx; zry[0] = zy; nbv[0] = agent;
@@ -1091,7 +1097,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                             visit(j);
                         }
                     }
-                    const float zx = xi - xFx, zy = yi - xFy;
+                    const float zx = (xi - xFx) - xLx, zy = (yi - xFy) - xLy;
                     const float gsc = __builtin_amdgcn_rsqf(fmaf(zy, zy, zx * zx)) * delta_i * a.ghost_factor;
                     float *zr = a.z + (so + wga0 + lane) * (size_t)((K + 1) * zc);
                     int *nb = a.nbr_idx + (so + wga0 + lane) * (size_t)(K + 1);
@@ -1242,7 +1248,7 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
 struct CArgs {
     int N, E, P, epb, kind;
     float u_max;
-    const float *xF, *d_hat, *radius, *pos;
+    const float *xF, *xF_lo, *d_hat, *radius, *pos;
     float *act;
 };
 
@@ -1270,10 +1276,11 @@ __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
     float2 *spos = reinterpret_cast<float2 *>(smem);                         // [epb][N]
     float *srad = reinterpret_cast<float *>(spos + (size_t)a.epb * N);       // [WL ? nwaves : 1][N]
     float *srad_w = srad + (WL ? (size_t)wave * N : 0);
-    float xi = 0.f, yi = 0.f, xFx = 0.f, xFy = 0.f, dhat = 1.f, ri = 0.f;
+    float xi = 0.f, yi = 0.f, xFx = 0.f, xFy = 0.f, xLx = 0.f, xLy = 0.f, dhat = 1.f, ri = 0.f;
     if (valid) {
         const float2 p = (reinterpret_cast<const float2 *>(a.pos) + wga0)[lane];
         const float2 g = reinterpret_cast<const float2 *>(a.xF)[(unsigned)agent];
+        if (a.xF_lo) { const float2 gl = reinterpret_cast<const float2 *>(a.xF_lo)[(unsigned)agent]; xLx = gl.x; xLy = gl.y; }
         dhat = a.d_hat[(unsigned)agent];
         ri = a.radius[(unsigned)agent];
         xi = p.x; yi = p.y; xFx = g.x; xFy = g.y;
@@ -1286,7 +1293,7 @@ __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
     if (!valid) return;
     float ux, uy;
     if (a.kind == DRONESIM_CONTROL_PROPORTIONAL) {
-        ux = xFx - xi; uy = xFy - yi;                                        // :667-668, k_gain = 1
+        ux = (xFx - xi) + xLx; uy = (xFy - yi) + xLy;                        // :667-668, k_gain = 1
         const float nrm = sqrtf(fmaf(uy, uy, ux * ux));
         if (nrm > a.u_max) { ux = ux / nrm * a.u_max; uy = uy / nrm * a.u_max; }   // :670-673
     } else {
@@ -1308,7 +1315,7 @@ __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
                 }
             }
         }
-        const float gx = 2.0f * (xi - xFx) - 0.1f * t2x, gy = 2.0f * (yi - xFy) - 0.1f * t2y;   // :633, :646
+        const float gx = 2.0f * ((xi - xFx) - xLx) - 0.1f * t2x, gy = 2.0f * ((yi - xFy) - xLy) - 0.1f * t2y;   // :633, :646
         ux = fminf(fmaxf(-gx, -a.u_max), a.u_max);                           // :647
         uy = fminf(fmaxf(-gy, -a.u_max), a.u_max);
     }
@@ -1691,7 +1698,7 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
 #if defined(DRONESIM_NO_UNIFORM)
     a.uniform = 0;
 #endif
-    a.xF = p->xF; a.d_hat = p->d_hat; a.delta = p->delta; a.radius = p->radius;
+    a.xF = p->xF; a.xF_lo = p->xF_lo; a.d_hat = p->d_hat; a.delta = p->delta; a.radius = p->radius;
     // far agents matter when a z row carries (v, l) of a tie-ordered agent (c = 5) or
     // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)
     const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
@@ -1899,7 +1906,7 @@ int dronesim_control(const DroneParams *p, int kind, const float *pos, float *ac
     const Geometry g = geometry(p->N, E);
     CArgs a{};
     a.N = p->N; a.E = E; a.P = g.P; a.epb = g.epb; a.kind = kind; a.u_max = u_max;
-    a.xF = p->xF; a.d_hat = p->d_hat; a.radius = p->radius; a.pos = pos; a.act = act;
+    a.xF = p->xF; a.xF_lo = p->xF_lo; a.d_hat = p->d_hat; a.radius = p->radius; a.pos = pos; a.act = act;
     const size_t nw = (size_t)g.threads / kWave;
     const size_t lds = sizeof(float2) * (size_t)g.epb * p->N + sizeof(float) * (g.P > 0 ? nw : 1) * p->N;
     hipStream_t s = static_cast<hipStream_t>(stream);

@@ -208,6 +208,8 @@ class drones:
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         self._xF = torch.tensor(self.end_points.reshape(N, 2), **f32).contiguous()
+        # what float32 drops of the float64 goal ring: the kernels subtract it after the (exact) float32 difference
+        self._xF_lo = torch.tensor(self.end_points.reshape(N, 2) - self._xF.double().cpu().numpy(), **f32).contiguous()
         self._d_hat = torch.tensor(self.d_safety, **f32)
         self._delta = torch.tensor(np.asarray(self.deltas, np.float64), **f32)
         self._radius = torch.tensor(self.drone_radius, **f32)
@@ -251,6 +253,7 @@ class drones:
             p.radius_min = float(self._radius.min().item())
             p.radius_max = float(self._radius.max().item())
             p.xF, p.d_hat = self._xF.data_ptr(), self._d_hat.data_ptr()
+            p.xF_lo = self._xF_lo.data_ptr()
             p.delta, p.radius = self._delta.data_ptr(), self._radius.data_ptr()
             self._params_cache = (key, p)
         return self._params_cache[1]

@@ -927,14 +927,30 @@ def test_degenerate_states_follow_the_reference_semantics(torch):
     np.testing.assert_array_equal(nb[0], ref["nbr_idx"][0])
     assert host(env.n_coll)[0] == ref["n_coll"][0] >= 2
     H.assert_close(host(env.reward)[0], ref["reward"][0], "coincident reward")
-    # on-goal agent: float32 goal == float32 position -> z_i = 0 -> NaN ghost rows on the GPU; the float64 oracle
-    # sees the float32-rounded goal a hair away, so only the GPU's own NaN pattern is asserted
+    # agent on its float32-ROUNDED goal: the float64 goal is a hair (~1e-7) away, and the kernel knows it (xF_lo): its
+    # offset and ghost rows follow the oracle's at the plain bar instead of collapsing to 0 / NaN
     zi = z[1, 2]
-    assert zi[0].tolist() == [0.0, 0.0]
-    ghost = nb[1, 2, 1:] < 0
-    assert np.isnan(zi[1:][ghost]).all() and np.isfinite(zi[1:][~ghost]).all()
+    assert 0 < np.abs(zi[0]).max() < 1e-6
+    H.assert_close(zi[0], ref["z"][1, 2, 0], "offset of the agent on its rounded goal", rtol=1e-6, atol=1e-13)
+    np.testing.assert_array_equal(nb[1], ref["nbr_idx"][1])
+    H.assert_close(z[1], ref["z"][1], "rows of the env with an agent on its rounded goal")
     assert np.isfinite(host(env.reward)[1]).all()
     np.testing.assert_array_equal(nb[2], ref["nbr_idx"][2])
+    # an agent EXACTLY on its goal (G = 20: agent 0's goal (19, 10) is a float32 number): z_i = 0, ghost rows NaN
+    # (drone_env.py:386 divides by |z_i|) on the GPU as in the reference
+    env3 = make_env(N, 20.0, 2, 2, np.ones(N), 1)
+    orc3 = Oracle(N, [20.0, 20.0], 2, np.ones(N), True)
+    p3 = (10 + (rng.random((1, N, 2)) - 0.5) * 12).astype(np.float32)
+    assert orc3.xF[0].tolist() == [19.0, 10.0]
+    p3[0, 0] = [19.0, 10.0]
+    env3.set_state(p3)
+    ref3 = orc3.observe(p3.astype(np.float64))
+    nb3, z3 = host(env3.nbr_idx), host(env3.z).reshape(1, N, 3, 2)
+    np.testing.assert_array_equal(nb3, ref3["nbr_idx"])
+    assert z3[0, 0, 0].tolist() == [0.0, 0.0]
+    ghost = nb3[0, 0, 1:] < 0
+    assert ghost.any() and np.isnan(z3[0, 0, 1:][ghost]).all() and np.isnan(ref3["z"][0, 0, 1:][ghost]).all()
+    assert np.isfinite(z3[0, 0, 1:][~ghost]).all() and np.isfinite(host(env3.reward)).all()
     # non-square grid
     env2 = drones(6, 0, [7, 4], "O", deltas=np.ones(6) * 0.8, simplify_zstate=True, n_envs=40, batched=True, seed=6)
     orc2 = Oracle(6, [7, 4], 2, np.ones(6) * 0.8, True)
@@ -946,6 +962,40 @@ def test_degenerate_states_follow_the_reference_semantics(torch):
     ref2 = orc2.observe(p1, host(act).astype(np.float64))
     safe = orc2.margins(p1) > H.MARGIN
     check_outputs(env2, None, ref2, safe, 2, None, "grid 7x4 ")
+
+
+@pytest.mark.parametrize("N,G,c", [(65, 31.03044823025579, 5), (256, 256.0, 2), (5, 5.0, 5)])
+def test_near_goal_offsets_keep_relative_accuracy(torch, N, G, c):
+    """Agents 1e-4 .. 0.3 from their goals on grids up to 256: the offset x - xF (z row 0), the arrival test and the
+    ghost direction (x - xF) / |x - xF| are taken from the float64 goal ring (DroneParams.xF_lo), so they meet the
+    oracle at float32 RELATIVE accuracy -- with a float32 goal the ghost row of an agent 0.04 from its goal was 2e-5
+    off at G = 31 (found by the shape fuzz, seed 13) and 1e-3 off at G = 256."""
+    k, E = 3, 64
+    deltas = np.ones(N) * 0.6
+    env = make_env(N, G, k, c, deltas, E, seed=3)
+    orc = Oracle(N, [G, G], k, deltas, c == 2, threads=4)
+    rng = np.random.default_rng(8)
+    r = 10.0 ** rng.uniform(-4, -0.5, (E, N, 1))
+    th = rng.uniform(0, 2 * np.pi, (E, N, 1))
+    pos = (orc.xF[None] + r * np.concatenate([np.cos(th), np.sin(th)], -1)).astype(np.float32)
+    env.set_state(pos)
+    p64 = pos.astype(np.float64)
+    ref = orc.observe(p64)
+    z = host(env.z).reshape(E, N, k + 1, c)
+    H.assert_close(z[:, :, 0, :2], ref["z"][:, :, 0, :2], "x - xF near the goal", rtol=3e-7, atol=1e-12)
+    safe = orc.margins(p64) > H.MARGIN
+    assert safe.mean() > 0.5
+    check_outputs(env, None, ref, safe, c, None, f"near goal N={N} ")
+    ghost = (ref["nbr_idx"] < 0)[safe]
+    assert ghost.any()                                       # ghost rows were compared (at the coordinate bar)
+    H.assert_close(z[..., :2][safe][ghost], ref["z"][..., :2][safe][ghost], "ghost rows near the goal", rtol=1e-5, atol=1e-6)
+    # the arrival test on the same states: one step with zero action
+    t0 = np.zeros(E, np.int32)
+    env.set_state(pos, None, t0)
+    res = env.step(torch.zeros(E, N, 2, device="cuda:0"))
+    inside = np.linalg.norm(orc.xF[None] - p64, axis=-1)
+    clear = (np.abs(inside - 0.2) > 1e-6).all(-1)
+    np.testing.assert_array_equal(host(res.finished)[clear].astype(bool), (inside <= 0.2).all(-1)[clear])
 
 
 @pytest.mark.parametrize("N,G", [(48, 24.0), (64, 28.0), (100, 100.0), (256, 256.0), (600, 600.0)])

@@ -64,7 +64,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == sorted(_native.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dronesim_version() == 200
+    assert lib.dronesim_version() == 201
     assert lib.dronesim_error_string(0) == b"ok"
     assert b"invalid" in lib.dronesim_error_string(_native.EINVAL)
 
@@ -74,7 +74,7 @@ def test_params_struct_layout_matches_header():
     body = header[header.index("typedef struct DroneParams {"):header.index("} DroneParams;")]
     names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|float)\s*\*?\s*(\w+);", body, re.M)
     assert names == [f[0] for f in _native.DroneParams._fields_]
-    assert C.sizeof(_native.DroneParams) == 4 * 4 + 11 * 4 + 4 + 4 * 8     # 4-byte pad before the pointers
+    assert C.sizeof(_native.DroneParams) == 4 * 4 + 11 * 4 + 4 + 5 * 8     # 4-byte pad before the pointers
 
 
 def test_episode_structs_match_header():
