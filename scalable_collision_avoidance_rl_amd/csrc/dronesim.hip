@@ -1574,9 +1574,15 @@ hipError_t launch_one(const KArgs &a, const Geometry &g, hipStream_t s)
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 255) dev = 0;
         std::lock_guard<std::mutex> lock(mu);
         if (!(opted[dev >> 6] >> (dev & 63) & 1ull)) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(drone_kernel<K, FAR, MODE, GEO, EPI>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            // the dynamic allowance is what the CU's 160 KiB leave next to the kernel's STATIC LDS: hipcc may promote a
+            // small per-lane array to LDS (256 B in the K = 7 episode-layer instantiations), and asking for all 160 KiB
+            // on top of that is refused
+            const void *fn = reinterpret_cast<const void *>(drone_kernel<K, FAR, MODE, GEO, EPI>);
+            hipFuncAttributes fa{};
+            hipError_t e = hipFuncGetAttributes(&fa, fn);
             if (e != hipSuccess) return e;   // reported by launch() through dronesim_last_error()
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
+            if (e != hipSuccess) return e;
             opted[dev >> 6] |= 1ull << (dev & 63);
         }
     }

@@ -1008,7 +1008,9 @@ int enable_big_lds(const void *kernel, unsigned long long (&opted)[4], std::mute
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 255) dev = 0;
     std::lock_guard<std::mutex> lock(mu);
     if (opted[dev >> 6] >> (dev & 63) & 1ull) return DRONESIM_OK;
-    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncAttributes fa{};                                        // 160 KiB per CU, minus what the kernel holds statically
+    hipError_t e = hipFuncGetAttributes(&fa, kernel);
+    if (e == hipSuccess) e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
     if (e != hipSuccess) {
         char msg[160];
         snprintf(msg, sizeof(msg), "cannot enable 160 KiB of dynamic LDS for %s: %s", what, hipGetErrorString(e));

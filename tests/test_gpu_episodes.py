@@ -145,6 +145,61 @@ def test_auto_reset_equals_step_then_masked_reset(torch, N, G, E, k, c):
         assert (rec["done_len"][::3] < 100).any()        # arrival-terminated episodes are short
 
 
+def test_episode_layer_shape_fuzz(torch):
+    """Seeded random shapes (N 2..300, k 1..8, c 2 / 5, uniform / heterogeneous / default Delta, ragged E) through the
+    episode layer: auto_reset == step + reset(mask=done) bit for bit over staggered episode ends, and the fused
+    random-action rollout with auto_reset == the same steps launched one by one."""
+    import os
+    from scalable_collision_avoidance_rl_amd import formation_O
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 5)))
+    iters, ran, ends = int(os.environ.get("FUZZ_ITERS", 10)), 0, 0
+    for it in range(iters):
+        N = int(rng.choice([2, 3, 5, 7, 16, 31, 32, 33, 48, 63, 64, 65, 100, 128, 200, 300]))
+        k = int(rng.integers(1, min(N - 1, 8) + 1)); c = int(rng.choice([2, 2, 5]))
+        G = float(max(6.0, 0.45 * N + 2 * rng.random()))
+        d_hat = formation_O(N, [G, G])[1]
+        if d_hat.min() <= 0.05:
+            continue
+        mode = rng.choice(["uniform", "hetero", "none"])
+        deltas = (np.ones(N) * float(rng.uniform(0.2, 0.95)) * d_hat.min() if mode == "uniform"
+                  else rng.uniform(0.1, 1.3, N) * d_hat.min() if mode == "hetero" else d_hat.copy())
+        E = int(rng.integers(1, 40)) if N > 64 else int(rng.integers(1, 150))
+        seed = int(rng.integers(1, 1 << 30))
+        tag = f"episode fuzz#{it} N={N} k={k} c={c} G={G:.2f} {mode} E={E}"
+        A = make_env(N, G, E, k=k, c=c, deltas=deltas, seed=seed, auto_reset=True)
+        B = make_env(N, G, E, k=k, c=c, deltas=deltas, seed=seed, track_episodes=True)
+        t0 = torch.tensor(rng.integers(185, 200, E).astype(np.int32), device="cuda:0")
+        A.t.copy_(t0); B.t.copy_(t0)
+        g = torch.Generator(device="cuda:0").manual_seed(it)
+        for s in range(18):
+            act = torch.rand(E, N, 2, device="cuda:0", generator=g) * 2 - 1
+            ra = A.step(act); rb = B.step(act, copy=True)
+            done = rb.finished.bool()
+            ends += int(done.sum())
+            if bool(done.any()):
+                B.reset(renew_obstacles=False, mask=done)
+            for name, x, y in (("reward", ra.rewards, rb.rewards), ("n_coll", ra.n_collisions, rb.n_collisions), ("done", ra.finished, rb.finished)):
+                assert torch.equal(x, y), (tag, s, name)
+            for name in ("pos", "vel", "t", "z", "nbr_idx", "episode"):
+                x, y = getattr(A, name), getattr(B, name)
+                assert torch.equal(x, y) or (name == "z" and torch.equal(torch.nan_to_num(x, nan=7.0), torch.nan_to_num(y, nan=7.0))), (tag, s, name)
+            assert torch.equal(A.episode_acc, B.episode_acc), (tag, s)
+        # fused rollout with in-kernel actions and resets == the same steps one by one
+        C1 = make_env(N, G, E, k=k, c=c, deltas=deltas, seed=seed, auto_reset=True)
+        C2 = make_env(N, G, E, k=k, c=c, deltas=deltas, seed=seed, auto_reset=True)
+        C1.t.copy_(t0); C2.t.copy_(t0)
+        T = 12
+        out = C1.rollout_random(T, record_actions=True)
+        for s in range(T):
+            r2 = C2.step(out["actions"][s])
+            assert torch.equal(r2.rewards, out["reward"][s]) and torch.equal(r2.finished, out["done"][s]), (tag, "rollout", s)
+        for name in ("pos", "vel", "t", "episode"):
+            assert torch.equal(getattr(C1, name), getattr(C2, name)), (tag, "rollout", name)
+        assert torch.equal(C1.episode_acc, C2.episode_acc), (tag, "rollout records")
+        ran += 1
+    assert ran >= iters // 2 and ends >= ran                     # shapes were run and episodes did end inside them
+
+
 def test_auto_reset_first_state_matches_the_oracle_reset(torch):
     """The fresh state an env gets from the in-kernel reset is the oracle's `reset` draw for that episode counter."""
     N, G, E = 64, 28.0, 64

@@ -723,6 +723,40 @@ def test_batched_policy_split_precisions_hold_the_float32_bar(torch, prec):
             H.assert_close(host(a3), host(a1), f"Gaussian samples {prec} vs f32", rtol=1e-4, atol=1e-4)
 
 
+def test_policy_shape_fuzz_all_precisions(torch):
+    """Seeded random network shapes (d_in 1..16, h1 / h2 1..512 incl. non-multiples of 32 and fewer chunks than waves,
+    nout 1..32, 1..6 agents, ragged E incl. 1) through every policy arithmetic against float64: exact-f32, bf16x3 and
+    f16x2 at the 1e-5 bar, plain bf16 at its own 3e-2."""
+    import os
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 7)))
+    g = torch.Generator().manual_seed(int(os.environ.get("FUZZ_SEED", 7)))
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1)
+    for it in range(int(os.environ.get("FUZZ_ITERS", 12))):
+        d = int(rng.integers(1, 17)); N = int(rng.integers(1, 7)); E = int(rng.choice([1, 2, 31, 63, 64, 65, 130, 257]))
+        h1 = int(rng.choice([1, 5, 31, 32, 33, 64, 96, 100, 128, 200, 257, 400, 512]))
+        h2 = int(rng.choice([1, 7, 32, 33, 64, 65, 96, 127, 128, 129, 300, 416, 480, 512]))
+        kind = int(rng.integers(0, 3))
+        nout = 4 if kind == 2 else int(rng.integers(1, 33))
+        sc1, sc2, sc3 = 0.8 / np.sqrt(d), 1.2 / np.sqrt(h1), 1.2 / np.sqrt(h2)
+        w = (r(N, d, h1) * sc1, r(N, h1) * 0.3, r(N, h1, h2) * sc2, r(N, h2) * 0.3, r(N, h2, nout) * sc3, r(N, nout) * 0.3)
+        x = r(E, N, d) * 3
+        W = [t.double() for t in w]
+        h = torch.relu(torch.einsum("end,ndh->enh", x.double(), W[0]) + W[1])
+        h = torch.relu(torch.einsum("enh,nhk->enk", h, W[2]) + W[3])
+        y = torch.einsum("enk,nko->eno", h, W[4]) + W[5]
+        ref = (y if kind == 0 else torch.softmax(y, -1) if kind == 1
+               else torch.cat([torch.tanh(y[..., :2]), torch.sigmoid(y[..., 2:])], -1)).numpy()
+        tag = f"policy fuzz#{it} d={d} h1={h1} h2={h2} nout={nout} kind={kind} N={N} E={E}"
+        for prec in ("f32", "bf16x3", "f16x2", "bf16"):
+            pol = BatchedMLP(*w, out_kind=kind, sample_kind=0, precision=prec)
+            out = host(pol.forward(x.cuda()))
+            if prec == "bf16":
+                H.assert_close(out, ref, f"{tag} {prec}", rtol=3e-2, atol=3e-2 * max(1.0, float(np.abs(ref).max())))
+            else:
+                H.assert_close(out, ref, f"{tag} {prec}", rtol=2e-5, atol=1e-5 * max(1.0, float(np.abs(ref).max())))
+
+
 def test_policy_rollout_loop_under_graph_replay(torch):
     """obs -> sample_action -> step captured in a hipGraph: the sampling stream is keyed by the env's
     device-side t / episode counters, so every replayed step draws new actions."""
