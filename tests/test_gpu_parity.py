@@ -628,6 +628,50 @@ def test_returns_and_advantage(torch):
         mc_returns(torch.zeros(2, 2, 2), 0.9)
 
 
+def test_learner_reductions_and_controllers_shape_fuzz(torch):
+    """Seeded random shapes through dronesim_returns / dronesim_advantage (T 1..40, ragged E x N, k 1..8, ghost ids,
+    random episode boundaries, gamma 0.5..1) and dronesim_control (N 2..300, both controllers) against the oracle."""
+    import os
+    from oracle.oracle import mc_returns as o_ret, neighbour_advantage as o_adv
+    from scalable_collision_avoidance_rl_amd.rollout_buffer import mc_returns, neighbour_advantage
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 9)))
+    dev = "cuda:0"
+    for it in range(int(os.environ.get("FUZZ_ITERS", 20))):
+        T, E, N = int(rng.integers(1, 41)), int(rng.integers(1, 7)), int(rng.choice([2, 3, 5, 17, 64, 65, 130]))   # (Python-loop oracle)
+        K1 = int(rng.integers(1, min(N - 1, 8) + 1)) + 1
+        gamma = float(rng.uniform(0.5, 1.0))
+        r = rng.normal(0, 3, (T, E, N)).astype(np.float32)
+        V = rng.normal(0, 5, (T, E, N)).astype(np.float32)
+        done = (rng.random((T, E)) < 0.08).astype(np.uint8) if rng.random() < 0.7 else None
+        nbr = rng.integers(0, N, (T, E, N, K1)).astype(np.int32)
+        nbr[..., 0] = np.arange(N)[None, None]
+        nbr[rng.random(nbr.shape) < 0.25] = -1                      # ghost slots
+        nbr[..., 0] = np.arange(N)[None, None]
+        tag = f"learner fuzz#{it} T={T} E={E} N={N} K1={K1} gamma={gamma:.3f} done={done is not None}"
+        dt = None if done is None else torch.tensor(done, device=dev)
+        G = mc_returns(torch.tensor(r, device=dev), gamma, dt)
+        ref_G = o_ret(r, gamma, done)
+        H.assert_close(host(G), ref_G, tag + " returns", rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_G).max())))
+        w = neighbour_advantage(G, torch.tensor(V, device=dev), torch.tensor(nbr, device=dev), gamma, dt)
+        ref_w = o_adv(host(G).astype(np.float64), V, nbr, gamma, done)
+        H.assert_close(host(w), ref_w, tag + " advantage", rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_w).max())))
+        # controllers on a random state of a random env shape
+        Nc = int(rng.choice([2, 3, 5, 16, 33, 64, 65, 128, 300])); Gc = float(max(6.0, 0.45 * Nc + 2 * rng.random())); Ec = int(rng.integers(1, 50))
+        env = make_env(Nc, Gc, 1, 2, np.ones(Nc) * 0.3, Ec, seed=it)
+        orc = Oracle(Nc, [Gc, Gc], 1, np.ones(Nc) * 0.3, True, threads=4)
+        pos = (Gc / 2 + (rng.random((Ec, Nc, 2)) - 0.5) * 0.9 * Gc).astype(np.float32)
+        env.set_state(pos)
+        p64 = pos.astype(np.float64)
+        H.assert_close(host(env.control("proportional")), orc.proportional_control(p64), f"fuzz#{it} prop N={Nc}")
+        d = np.linalg.norm(p64[:, :, None] - p64[:, None], axis=-1) - 0.2
+        d[:, np.arange(Nc), np.arange(Nc)] = 1e9
+        safe = (np.minimum(np.abs(d), np.abs(d - orc.d_hat[None, :, None])).min(axis=(1, 2)) > 1e-2)
+        if safe.any():
+            u = float(rng.uniform(0.3, 1.0))
+            H.assert_close(host(env.control("gradient", u))[safe], orc.gradient_control(p64, u)[safe], f"fuzz#{it} grad N={Nc}",
+                           atol=H.ATOL + 0.1 * 2e-7 / 1e-2 ** 2)
+
+
 # ------------------------------------------------------------------------------- batched policies (SURVEY 8f-1)
 class _L:      # minimal stand-in exposing .weight [out,in] / .bias like torch.nn.Linear
     def __init__(self, w_in_out, b):
