@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <type_traits>
 
@@ -619,9 +620,15 @@ __global__ void __launch_bounds__(256, NC1 <= 8 ? 4 : 3) mlp3_bf16_kernel(const 
 // tools/micro/mfma_dma.hip): the matrix pipe is ~70 % busy at the ACTUAL shader clock, and that clock is what gives:
 // 2.07 GHz with the weight stream switched off, 1.6 GHz with it on (power management), against 2.4 GHz nominal --
 // ring depth 3 / 4 / 5, spreading the roles over the SIMDs and L1-resident weights all leave the time unchanged.
-constexpr int kTilesX = 2;                 // row tiles per wave: every weight fragment loaded feeds all of them
-constexpr int kRowsX = 32 * kTilesX;       // env rows per workgroup
-constexpr int kRingX = 4;                  // stages of the per-wave weight ring in LDS
+// TILES row tiles of 32 env rows per wave: every weight fragment loaded feeds all of them.  2 = 64-row workgroups, two per
+// CU (256 registers per wave) -- the instantiated one; 4 = 128-row workgroups, one per CU, would halve the weight bytes
+// per matrix instruction with the 256 accumulator registers of a wave in the AGPR half of its 512 (see launch below).
+constexpr int kStreamPadX = 8;             // zero stages behind every stream: the run-ahead requests of the deepest ring
+__host__ __device__ constexpr int split_ring_depth(int tiles) { return tiles <= 2 ? 4 : 8; }   // stages of the per-wave weight ring in LDS
+template <int N, int I = 0, class F> __device__ __forceinline__ void for_each_slot(F &f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); for_each_slot<N, I + 1>(f); }
+}
 
 struct MArgsX {
     int E, N, d_in, h1, h2, nc1, nc2;
@@ -692,9 +699,10 @@ struct SchemeF16x2 {                                   // v = hi + lo to 2^-22 (
 
 // relu + split of half an accumulator tile (registers 8 HALF .. 8 HALF + 7 = the k slots of k-step HALF of the next
 // layer's B operand), dealt out over the slots between a stage's matrix instructions: one call per slot.
-template <class S, int HALF>
+template <class S, int HALF, int TILES>
 struct SplitJob {
-    static constexpr int kSlots = 2 * S::kProducts;
+    static constexpr int kSlots = TILES * S::kProducts;
+    static constexpr int kStride = (kSlots - 2) / 4 > 0 ? (kSlots - 2) / 4 : 1;    // pairs behind slots 1, 1 + stride, ...
     const f32x16 &src;
     Parts<S::kParts> &dst;
     __device__ __forceinline__ SplitJob(const f32x16 &s, Parts<S::kParts> &d) : src(s), dst(d) {}
@@ -707,20 +715,13 @@ struct SplitJob {
     }
     template <int SLOT> __device__ __forceinline__ void slot()
     {
-        if constexpr (kSlots >= 12) {                  // twelve slots: a pair behind slots 1, 3, 5, 7
-            if constexpr (SLOT == 1) pair<0>();
-            if constexpr (SLOT == 3) pair<1>();
-            if constexpr (SLOT == 5) pair<2>();
-            if constexpr (SLOT == 7) pair<3>();
-        } else {                                       // six slots: a pair behind slots 1 .. 4
-            if constexpr (SLOT >= 1 && SLOT <= 4) pair<SLOT - 1>();
-        }
+        if constexpr (SLOT >= 1 && (SLOT - 1) % kStride == 0 && (SLOT - 1) / kStride < 4) pair<(SLOT - 1) / kStride>();
     }
     __device__ __forceinline__ void all() { pair<0>(); pair<1>(); pair<2>(); pair<3>(); }
 };
 struct NoJob { template <int SLOT> __device__ __forceinline__ void slot() {} };
 #ifdef DRONESIM_ABL_X3_NOSPLIT
-template <class S, int HALF> struct NoSplitJob {
+template <class S, int HALF, int TILES> struct NoSplitJob {
     __device__ __forceinline__ NoSplitJob(const f32x16 &s, Parts<S::kParts> &d) { d.p[0][0] += (unsigned)s[8 * HALF]; }
     template <int SLOT> __device__ __forceinline__ void slot() {}
 };
@@ -766,10 +767,11 @@ template <int P> __device__ __forceinline__ Parts<P> parts_from_lds(const char *
 #define X3_RING_READ(dst, p) dst = *reinterpret_cast<const u32x4 *>(p)
 #endif
 
-template <class S>
-__global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int E, int N, int d_in, const MArgsX rest)
+template <class S, int TILES>
+__global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(const float *x, int E, int N, int d_in, const MArgsX rest)
 {
     constexpr int P = S::kParts, kStageBytes = P * 1024;
+    constexpr int kTilesX = TILES, kRowsX = 32 * TILES, kRingX = split_ring_depth(TILES);
     MArgsX a = rest;
     a.x = x; a.E = E; a.N = N; a.d_in = d_in;
     constexpr int kMaxChunks = 4;                        // layer-2 chunks per wave: h2 <= 512
@@ -814,10 +816,15 @@ __global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int 
 #pragma unroll
         for (int p = 0; p < P; ++p) dp[64 * p] = xp.p[p];
     }
-    uint32_t tval = 0, epval = 0;
-    if (e0 + (tid >> 2) < a.E && a.fin.sample_kind != 0) {          // of the row this thread finishes (4 lanes per row)
-        if (a.fin.t_dev) tval = (uint32_t)a.fin.t_dev[e0 + (tid >> 2)];
-        if (a.fin.episode_dev) epval = (uint32_t)a.fin.episode_dev[e0 + (tid >> 2)];
+    uint32_t tval[kRowsX / 64], epval[kRowsX / 64];                // step / episode counters of the rows this thread finishes
+#pragma unroll
+    for (int r = 0; r < kRowsX / 64; ++r) {                        // (the sampling stream's position; 4 lanes per row)
+        const int e = e0 + 64 * r + (tid >> 2);
+        tval[r] = epval[r] = 0;
+        if (e < a.E && a.fin.sample_kind != 0) {
+            if (a.fin.t_dev) tval[r] = (uint32_t)a.fin.t_dev[e];
+            if (a.fin.episode_dev) epval[r] = (uint32_t)a.fin.episode_dev[e];
+        }
     }
     for (int idx = tid; idx < nb + 32; idx += 256) {               // biases -> LDS, zero padded
         float v = 0.0f;
@@ -872,28 +879,21 @@ __global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int 
         const char *np = ring + nslot * kStageBytes + lane * 16;
         X3_PIN();
         auto slot_work = [&](auto SLOT) {
-            constexpr int s = decltype(SLOT)::value, q = s >> 1;
-            acc[s & 1] = S::mfma(wf[S::w_part(q)], b[s & 1].p[S::b_part(q)], acc[s & 1]);
+            constexpr int s = decltype(SLOT)::value, q = s / TILES, t = s % TILES;
+            acc[t] = S::mfma(wf[S::w_part(q)], b[t].p[S::b_part(q)], acc[t]);
             X3_PIN();
-            if constexpr (s & 1) {
+            if constexpr (t == TILES - 1) {
 #pragma unroll
                 for (int p = 0; p < P; ++p)
                     if (S::last_use(p) == q) X3_RING_READ(wf[p], np + p * 1024);
             }
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                if (S::request_slot(p) == s) { request_part(p); if (p == P - 1) request_done(); }
+                if (S::request_slot(p) * TILES / 2 == s) { request_part(p); if (p == P - 1) request_done(); }
             job.template slot<s>();
             X3_PIN();
         };
-        slot_work(std::integral_constant<int, 0>{}); slot_work(std::integral_constant<int, 1>{});
-        slot_work(std::integral_constant<int, 2>{}); slot_work(std::integral_constant<int, 3>{});
-        slot_work(std::integral_constant<int, 4>{}); slot_work(std::integral_constant<int, 5>{});
-        if constexpr (S::kProducts == 6) {
-            slot_work(std::integral_constant<int, 6>{}); slot_work(std::integral_constant<int, 7>{});
-            slot_work(std::integral_constant<int, 8>{}); slot_work(std::integral_constant<int, 9>{});
-            slot_work(std::integral_constant<int, 10>{}); slot_work(std::integral_constant<int, 11>{});
-        }
+        for_each_slot<S::kProducts * TILES>(slot_work);
         nslot = nslot + 1 == kRingX ? 0 : nslot + 1;
         X3_PIN();
     };
@@ -918,18 +918,20 @@ __global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int 
             for (int t = 0; t < kTilesX; ++t) { a1[t] = bias_tile(sbias, lane); xB[t] = parts_from_lds<P>(sxb + t * kStageBytes + lane * 16); }
             stage(a1, xB, nojob);
 #pragma unroll
-            for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0> j(a1[t], hB0[t]); j.all(); }
+            for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0, TILES> j(a1[t], hB0[t]); j.all(); }
         }
         for (int c1 = 0; c1 < NC1; ++c1) {
             // k-step 2 c1 of every chunk of mine; meanwhile the other half of a1 becomes hB1 (tile i in stage i)
 #pragma unroll
             for (int i = 0; i < kMaxChunks; ++i) {
                 if (i < nmine) {                                   // wave-uniform
-                    if (i < kTilesX) { SplitJobInStage<S, 1> j(a1[i], hB1[i]); stage(acc2[i], hB0, j); }
+                    if (i < kTilesX) { SplitJobInStage<S, 1, TILES> j(a1[i], hB1[i]); stage(acc2[i], hB0, j); }
                     else stage(acc2[i], hB0, nojob);
                 }
             }
-            if (nmine < kTilesX) { SplitJob<S, 1> j(a1[1], hB1[1]); j.all(); }
+#pragma unroll
+            for (int t = 0; t < kTilesX; ++t)                     // tiles no stage of mine has dealt with (fewer chunks than tiles)
+                if (t >= nmine) { SplitJob<S, 1, TILES> j(a1[t], hB1[t]); j.all(); }
             if (c1 + 1 < NC1) {                                    // layer 1 of the next chunk
                 Parts<P> xB[kTilesX];
                 a1[0] = bias_tile(sbias + (c1 + 1) * 32, lane);
@@ -941,11 +943,13 @@ __global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int 
 #pragma unroll
             for (int i = 0; i < kMaxChunks; ++i) {
                 if (i < nmine) {
-                    if (i < kTilesX) { SplitJobInStage<S, 0> j(a1[i], hB0[i]); stage(acc2[i], hB1, j); }
+                    if (i < kTilesX) { SplitJobInStage<S, 0, TILES> j(a1[i], hB0[i]); stage(acc2[i], hB1, j); }
                     else stage(acc2[i], hB1, nojob);
                 }
             }
-            if (nmine < kTilesX) { SplitJob<S, 0> j(a1[1], hB0[1]); j.all(); }
+#pragma unroll
+            for (int t = 0; t < kTilesX; ++t)
+                if (t >= nmine) { SplitJob<S, 0, TILES> j(a1[t], hB0[t]); j.all(); }
         }
 
         // ---- layer 3 from the finished layer-2 accumulators, same stream
@@ -954,10 +958,10 @@ __global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int 
             if (i < nmine) {
                 Parts<P> pB[kTilesX];
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0> j(acc2[i][t], pB[t]); j.all(); }
+                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0, TILES> j(acc2[i][t], pB[t]); j.all(); }
                 stage(y, pB, nojob);
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 1> j(acc2[i][t], pB[t]); j.all(); }
+                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 1, TILES> j(acc2[i][t], pB[t]); j.all(); }
                 stage(y, pB, nojob);
             }
         }
@@ -978,8 +982,9 @@ __global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int 
             spart[((size_t)wave * kRowsX + t * 32 + (lane & 31)) * 33 + cd_row(r, lane)] = y[t][r];
     __syncthreads();
 
-    {                                                              // activation + sampling: four lanes per env row
-        const int row = tid >> 2, part = tid & 3;
+#pragma unroll
+    for (int r = 0; r < kRowsX / 64; ++r) {                        // activation + sampling: four lanes per env row
+        const int row = 64 * r + (tid >> 2), part = tid & 3;
         const int e = e0 + row;
         if (e >= a.E) return;
         float yv[kQ];
@@ -994,7 +999,7 @@ __global__ void __launch_bounds__(256, 2) mlp3_split_kernel(const float *x, int 
             }
             yv[i] = v;
         }
-        finish_quad(a.fin, yv, e, agent, part, tval, epval);
+        finish_quad(a.fin, yv, e, agent, part, tval[r], epval[r]);
     }
 }
 #undef X3_PIN
@@ -1108,11 +1113,31 @@ extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, 
     return DRONESIM_OK;
 }
 
-// stages per (agent, wave) stream: wave 0 owns the most chunks; + kRingX of padding for the run-ahead requests
+// stages per (agent, wave) stream: wave 0 owns the most chunks; + padding for the run-ahead requests
 extern "C" int dronesim_mlp_bf16x3_stages(int h1, int h2)
 {
     const int nc1 = (h1 + 31) / 32, nc2 = (h2 + 31) / 32, nm = (nc2 + 3) / 4;
-    return nc1 * (1 + 2 * nm) + 2 * nm + kRingX;
+    return nc1 * (1 + 2 * nm) + 2 * nm + kStreamPadX;
+}
+
+template <class S, int TILES>
+int launch_split(const MArgsX &a, int N, hipStream_t stream)
+{
+    constexpr size_t stage_bytes = S::kParts * 1024, rows = 32 * TILES;
+    const size_t part_bytes = sizeof(float) * 4 * rows * 33, ring_bytes = (size_t)4 * split_ring_depth(TILES) * stage_bytes;   // share LDS
+    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32) + TILES * stage_bytes +
+                       (part_bytes > ring_bytes ? part_bytes : ring_bytes);
+    if (lds > 48 * 1024) {
+        static std::mutex mu;
+        static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
+        const int rc = enable_big_lds(reinterpret_cast<const void *>(mlp3_split_kernel<S, TILES>), opted, mu, "mlp3_split_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL((mlp3_split_kernel<S, TILES>), dim3(((a.E + rows - 1) / rows) * N), dim3(256), lds, stream,
+                       a.x, a.E, a.N, a.d_in, a);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
 }
 
 template <class S>
@@ -1145,15 +1170,10 @@ int mlp_forward_split(const char *what, const DroneMlpBf16 *m, const float *x, f
     a.trace = g_policy_trace;
 #endif
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
-    constexpr size_t stage_bytes = S::kParts * 1024;
-    const size_t part_bytes = sizeof(float) * 4 * kRowsX * 33, ring_bytes = (size_t)4 * kRingX * stage_bytes;   // the two share LDS
-    const size_t lds = sizeof(float) * (32 * (size_t)(a.nc1 + a.nc2) + 32) + kTilesX * stage_bytes +
-                       (part_bytes > ring_bytes ? part_bytes : ring_bytes);
-    hipLaunchKernelGGL(mlp3_split_kernel<S>, dim3(((E + kRowsX - 1) / kRowsX) * m->N), dim3(256), lds,
-                       static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
-    const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
-    return DRONESIM_OK;
+    // TILES = 4 (128-row workgroups, one per CU, accumulators in the AGPR half of a 512-register wave) builds and is
+    // correct, but hipcc 7.2 places the accumulators badly (1100 v_accvgpr copies, scratch spills whose waits drain the
+    // DMA ring): 561 vs 301 us at C3 Gaussian f16x2.  Not instantiated; it needs hand-placed AGPR accumulators.
+    return launch_split<S, 2>(a, m->N, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
