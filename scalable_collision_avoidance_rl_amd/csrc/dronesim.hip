@@ -1111,13 +1111,17 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                             const float2 pj = spos_env[j];
                             rx = pj.x - xi; ry = pj.y - yi;
                         }
-                        nb[kth] = kth == 0 ? agent : (real ? (int)j : -1);
+                        // streaming stores like every other output: plain ones would leave the rows dirty in L2 and the
+                        // launch would end with their write-back (a launch in which every env restarts: 47 -> see DESIGN 3.3)
+                        st_out(nb + kth, kth == 0 ? agent : (real ? (int)j : -1));
                         float *row = zr + kth * zc;
-                        row[0] = rx; row[1] = ry;
                         if (zc == 5) {
-                            if (kth == 0) { row[2] = 0.f; row[3] = 0.f; row[4] = li; }
-                            else if (hv) { row[2] = 0.f; row[3] = 0.f; row[4] = uni_args ? a.radius_u : sconst[j].y; }
-                            else { row[2] = row[3] = row[4] = __builtin_nanf(""); }
+                            st_out(row + 0, rx); st_out(row + 1, ry);          // 20-byte rows: 4-byte aligned only
+                            if (kth == 0) { st_out(row + 2, 0.f); st_out(row + 3, 0.f); st_out(row + 4, li); }
+                            else if (hv) { st_out(row + 2, 0.f); st_out(row + 3, 0.f); st_out(row + 4, uni_args ? a.radius_u : sconst[j].y); }
+                            else { const float qn = __builtin_nanf(""); st_out(row + 2, qn); st_out(row + 3, qn); st_out(row + 4, qn); }
+                        } else {
+                            st_out2(row, rx, ry);
                         }
                     }
                     if (MODE != kRollout || step == nsteps - 1) {
