@@ -9,10 +9,11 @@ envs whose episode ends (200 steps, drone_env.py:30) reset + re-observed inside 
 (train_problem.py:132).  Actions are synthetic U(-1,1)^2 (RandomAgent, SAC_agents.py:22),
 pre-generated and resident in HBM before the timed region.
 
-Timing: the K requested steps are captured ONCE as a hipGraph (whatever K is) and the timed region
-replays that graph `repeats` times -- enough for >= 0.5 s -- between the two barriers, so a short
-`--steps 20` run measures the same thing as a long one: value = N * E * K * repeats / elapsed and
-ms_per_step = elapsed / (K * repeats).  Every ~200 steps the path's only exchange runs inside the
+Timing: the K requested steps are captured as ONE hipGraph (whatever K is; a short request several times
+over, ~1000 launches per graph, because a replay costs ~10 us of GPU idle time whatever it holds) and the
+timed region replays that graph `repeats` times -- enough for >= 0.5 s -- between the two barriers, so a
+short `--steps 20` run measures the same thing as a long one: value = N * E * timed_steps / elapsed and
+ms_per_step = elapsed / timed_steps, timed_steps = K * graph_copies * repeats.  Every ~200 steps the path's only exchange runs inside the
 timed region: one fixed-order reduction of the per-env episode records + one all-gather (RCCL).
 
 Default workload = BASELINE.json configs[2] (N=64 x E=4096 per GPU, Delta=1.0, G=28): the
@@ -218,9 +219,13 @@ def main():
             while step_no % T_ep:                   # plain path resets by step index: align the capture to an episode
                 one_step(step_no); step_no += 1
         torch.cuda.synchronize()
+        # a replay costs ~10 us of GPU idle time whatever the graph holds: a short request is captured several times
+        # over into ONE graph of ~1000 launches (the episode layer keeps every counter on the device, so the copies
+        # simply continue the rollout), and the per-step figure of `--steps 20` is that of `--steps 2000`
+        copies = max(1, -(-1000 // K)) if layer else 1
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for s in range(K):
+            for s in range(K * copies):
                 one_step(s)
         for _ in range(2):                          # untimed replays: instantiate + clocks
             graph.replay()
@@ -233,8 +238,9 @@ def main():
             one = float(o.item())
         repeats = max(1, int(np.ceil(1.2 * args.min_seconds / one)))
     else:
-        repeats = 1
-    log_every = max(1, T_ep // K) if K < T_ep else 1     # replays between two exchanges (~ once per episode)
+        repeats, copies = 1, 1
+    L = K * copies                                       # launches per replay
+    log_every = max(1, T_ep // L) if L < T_ep else 1     # replays between two exchanges (~ once per episode)
 
     barrier()
     t0 = time.perf_counter()
@@ -252,7 +258,7 @@ def main():
             work.wait()
     barrier()
     elapsed = time.perf_counter() - t0
-    total_steps = K * repeats
+    total_steps = L * repeats
     # final exchange: global per-episode figures (the same reduction + all-gather as inside the timed region)
     summary = reduce_episode_records(env)
     summary["exchanges_in_timed_region"] = len(exchanges)
@@ -324,12 +330,13 @@ def main():
         out = {
             "metric": "env agent-steps/sec (n_agents x n_envs x steps)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "repeats": repeats, "timed_steps": total_steps, "timed_seconds": elapsed,
+            "repeats": repeats, "graph_copies": copies, "timed_steps": total_steps, "timed_seconds": elapsed,
             "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "n_agents": N, "envs_per_gpu": e_gpu, "n_envs_total": E_global,
                        "grid": G, "delta": delta, "k_closest": 2, "simplify_zstate": True,
-                       "launch": (f"hipGraph of the {K} requested steps, replayed {repeats}x in the timed region" if graph is not None else "eager"),
+                       "launch": ((f"hipGraph of the {K} requested steps" + (f", captured {copies}x over ({L} launches)" if copies > 1 else "") +
+                                   f", replayed {repeats}x in the timed region") if graph is not None else "eager"),
                        "episode_layer": ("per-step statistic + in-kernel auto-reset (dronesim_step_ex)" if layer else
                                          "plain dronesim_step + reset kernel every 200 steps"),
                        "actions": "pre-generated U(-1,1)^2, resident in HBM" if policy is None else

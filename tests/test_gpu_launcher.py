@@ -65,7 +65,7 @@ def test_bench_py_runs_with_two_ranks_on_one_device():
     assert len(lines) == 1                                      # rank 0 only
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["n_envs_total"] == 1024 and out["config"]["parallelism"] == "env-shard x2"
-    assert out["steps"] == 30 and out["repeats"] >= 1 and out["timed_steps"] == 30 * out["repeats"]
+    assert out["steps"] == 30 and out["repeats"] >= 1 and out["timed_steps"] == 30 * out["graph_copies"] * out["repeats"]
     assert out["value"] == pytest.approx(64 * 1024 * out["timed_steps"] / out["timed_seconds"], rel=1e-9)
     st = out["episode_end_stats"]
     assert st["world_size"] == 2 and st["exchanges_in_timed_region"] >= 1 and st["agent_steps"] > 0

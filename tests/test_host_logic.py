@@ -147,9 +147,9 @@ def test_split_policy_boundary_without_a_gpu():
         m.d_in = 17
         assert fn(C.byref(m), one, nul, nul, nul, 0, 0, 0, nul, nul, 4, nul) == _native.EUNSUPPORTED
     # h1 = 40 -> 2 chunks, h2 = 72 -> 3 chunks: waves 0..2 own one chunk, wave 3 none; wave 0's stream is
-    # W1(0) W2(0,0) W1(1) W2(0,1) W2(1,0) W2(1,1) W3(0,0) W3(0,1) + 4 stages of padding
+    # W1(0) W2(0,0) W1(1) W2(0,1) W2(1,0) W2(1,1) W3(0,0) W3(0,1) + 8 stages of padding
     stages = lib.dronesim_mlp_bf16x3_stages(40, 72)
-    assert stages == 2 * (1 + 2 * 1) + 2 * 1 + 4
+    assert stages == 2 * (1 + 2 * 1) + 2 * 1 + 8
     g = torch.Generator().manual_seed(5)
     w1, w2, w3 = (torch.rand(*s, generator=g) * 2 - 1 for s in ((2, 6, 40), (2, 40, 72), (2, 72, 4)))
     for scheme, nparts, dtype in (("bf16x3", 3, torch.bfloat16), ("f16x2", 2, torch.float16)):
