@@ -154,6 +154,59 @@ def test_episode_c1_compat_mode(torch):
     print(env)
 
 
+def test_compat_face_shape_fuzz(torch):
+    """The reference-typed E = 1 face (live float64 `state`, lists of [k+1, c] arrays, `Ni` lists, Python bool) on seeded
+    random shapes (N 2..130, k 1..8, c 2 / 5, uniform / heterogeneous / default Delta): a few steps from an injected
+    state against the oracle, types and shapes as the reference returns them (drone_env.py:214-258, 336-401)."""
+    import os
+    from scalable_collision_avoidance_rl_amd import drones, formation_O
+    rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 17)))
+    ran = 0
+    for it in range(int(os.environ.get("FUZZ_ITERS", 12))):
+        N = int(rng.choice([2, 3, 5, 8, 21, 64, 65, 130]))
+        k = int(rng.integers(1, min(N - 1, 8) + 1)); c = int(rng.choice([2, 5]))
+        G = float(max(6.0, 0.45 * N + 2 * rng.random()))
+        d_hat = formation_O(N, [G, G])[1]
+        if d_hat.min() <= 0.05:
+            continue
+        mode = rng.choice(["uniform", "hetero", "none"])
+        deltas = (np.ones(N) * float(rng.uniform(0.2, 0.95)) * d_hat.min() if mode == "uniform"
+                  else rng.uniform(0.1, 1.3, N) * d_hat.min() if mode == "hetero" else None)
+        env = drones(n_agents=N, n_obstacles=0, grid=[G, G], end_formation="O", k_closest=k, deltas=deltas,
+                     simplify_zstate=(c == 2))
+        env.collision_weight = float(rng.uniform(0.05, 0.5))
+        orc = Oracle(N, [G, G], k, deltas, c == 2, collision_weight=env.collision_weight)
+        assert env.local_state_space == (k + 1) * c and env.state.shape == (N, 5) and env.state.dtype == np.float64
+        pos = (G / 2 + (rng.random((N, 2)) - 0.5) * 0.8 * G).astype(np.float32).astype(np.float64)
+        env.state[:, 0:2] = pos; env.state[:, 2:4] = 0.0
+        env.internal_t = int(rng.integers(0, 198))
+        tag = f"compat fuzz#{it} N={N} k={k} c={c} {mode}"
+        for s in range(3):
+            act = rng.uniform(-1, 1, (N, 2))
+            t_before = env.internal_t
+            new_state, new_z, r, n_coll, finished, tr = env.step([act[i] for i in range(N)])
+            assert new_state is env.state and isinstance(finished, bool) and isinstance(new_z, list) and len(new_z) == N
+            assert new_z[0].shape == (k + 1, c) and new_z[0].dtype == np.float64 and r.shape == (N,) and r.dtype == np.float64
+            assert env.internal_t == t_before + 1
+            p1 = new_state[None, :, 0:2].copy()
+            v1 = np.float32(act).astype(np.float64)[None]
+            ref = orc.observe(p1, v1)
+            safe = bool((orc.margins(p1) > H.MARGIN)[0])
+            H.assert_close(new_state[:, 2:4], v1[0], tag + " vel")
+            if not safe:
+                continue
+            H.assert_close(r, ref["reward"][0], tag + f" reward@{s}"); H.assert_close(tr, ref["true_reward"][0], tag + f" true_reward@{s}")
+            assert int(n_coll) == int(ref["n_coll"][0]), tag
+            want = [[int(j) for j in row if j >= 0] for row in ref["nbr_idx"][0]]
+            assert [[int(j) for j in lst] for lst in env.Ni] == want, tag
+            m = H.z_compare_mask(ref["nbr_idx"], np.ones((1, N), bool), c)[0]
+            H.assert_close(np.where(m, np.stack(new_z), 0), np.where(m, ref["z"][0], 0), tag + f" z@{s}", atol=H.atol_coord(G))
+            all_in = bool((np.linalg.norm(orc.xF - p1[0], axis=-1) <= 0.2).all())
+            assert finished == (all_in or t_before >= 199), tag
+        ran += 1
+    assert ran >= 6
+
+
 # ------------------------------------------------------------------------------- oracle, large batches
 CONFIGS = [
     # name,            N,   G,    k, c, deltas,        E,    box
