@@ -1,4 +1,4 @@
-"""CPU, world_size = 2 over gloo: the N > 1 path of the benchmark / rollout loop.
+"""CPU, world_size = 2 / 3 / 8 over gloo: the N > 1 path of the benchmark / rollout loop.
 
 Env-axis sharding has no data-path collective; the only exchange is the all-gather of the
 per-rank reward statistic (sharding.py).  Here two processes each own half of a batch whose
@@ -67,11 +67,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_statistic_equals_unsharded():
+@pytest.mark.parametrize("world", [2, 3, 8])          # even shards, ragged shards (12 envs over 3 x 4 ... over 8: 2,2,2,2,1,1,1,1), the node's 8
+def test_sharded_statistic_equals_unsharded(world):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
@@ -83,19 +84,22 @@ def test_sharded_statistic_equals_unsharded():
     for o in outs:
         st.add_step(torch.from_numpy(o["reward"]), torch.from_numpy(o["true_reward"]), torch.from_numpy(o["n_coll"]))
     want = summarize(st.vec.view(1, -1))
-    assert res[0][1:3] == (0, 6) and res[1][1:3] == (6, 12)
+    assert res[0][1] == 0 and res[-1][2] == E and all(res[i][2] == res[i + 1][1] for i in range(world - 1))   # contiguous cover
+    assert max(r[2] - r[1] for r in res) - min(r[2] - r[1] for r in res) <= 1
+    if world == 2:
+        assert res[0][1:3] == (0, 6) and res[1][1:3] == (6, 12)
     # shard invariance of the reset streams: rank r holds exactly its slice of the unsharded batch
-    np.testing.assert_array_equal(np.concatenate([res[0][3], res[1][3]]), node_full)
+    np.testing.assert_array_equal(np.concatenate([r[3] for r in res]), node_full)
     for r in res:
         got = r[4]
-        assert got["world_size"] == 2 and got["agent_steps"] == want["agent_steps"] == N * E * T
+        assert got["world_size"] == world and got["agent_steps"] == want["agent_steps"] == N * E * T
         for k in ("mean_reward", "mean_true_reward", "collisions_per_env_step"):
             assert got[k] == pytest.approx(want[k], rel=1e-12)
     # record-based exchange: the gathered per-rank totals reproduce the unsharded figures
     want_e = summarize_episodes(_episode_totals(0, E).view(1, -1), N)
     for r in res:
         got = r[5]
-        assert got["world_size"] == 2 and got["episodes"] == E and got["mean_episode_len"] == 7
+        assert got["world_size"] == world and got["episodes"] == E and got["mean_episode_len"] == 7
         for k in ("mean_episode_reward", "mean_episode_true_reward", "mean_episode_collisions", "mean_reward"):
             assert got[k] == pytest.approx(want_e[k], rel=1e-12), k
 
