@@ -26,21 +26,24 @@ def _launch(nproc, script, args, extra_env=None, timeout=600):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-@pytest.mark.parametrize("N,G,E,T", [(64, 28.0, 96, 70), (5, 5.0, 250, 70)])
-def test_two_ranks_own_their_shards_of_the_gpu_outputs(tmp_path, N, G, E, T):
-    """2 ranks x half the envs == 1 rank x all envs, bit for bit (states, observations, rewards, episode records), and
-    the all-gathered statistic of the 2-rank run equals the 1-rank one."""
+@pytest.mark.parametrize("N,G,E,T,W", [(64, 28.0, 96, 70, 2), (5, 5.0, 250, 70, 2), (64, 28.0, 99, 70, 4)])
+def test_ranks_own_their_shards_of_the_gpu_outputs(tmp_path, N, G, E, T, W):
+    """W ranks x their shard of the envs (ragged at 99 over 4) == 1 rank x all envs, bit for bit (states, observations,
+    rewards, episode records), and the all-gathered statistic of the W-rank run equals the 1-rank one."""
     worker = os.path.join("tests", "launch_worker.py")
     two, one = tmp_path / "two", tmp_path / "one"
     two.mkdir(); one.mkdir()
-    r = _launch(2, worker, [two, N, G, E, T])
+    r = _launch(W, worker, [two, N, G, E, T])
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([sys.executable, worker, str(one), str(N), str(G), str(E), str(T)], cwd=ROOT,
                        env=dict(os.environ, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     full = np.load(one / "rank0.npz")
-    parts = [np.load(two / f"rank{k}.npz") for k in range(2)]
-    assert [(int(p["lo"]), int(p["hi"])) for p in parts] == [(0, E // 2), (E // 2, E)]
+    parts = [np.load(two / f"rank{k}.npz") for k in range(W)]
+    bounds = [(int(p["lo"]), int(p["hi"])) for p in parts]
+    assert bounds[0][0] == 0 and bounds[-1][1] == E and all(bounds[i][1] == bounds[i + 1][0] for i in range(W - 1))
+    if W == 2:
+        assert bounds == [(0, E // 2), (E // 2, E)]
     for name in ("pos", "z", "nbr", "acc", "last_reward"):
         assert np.array_equal(np.concatenate([p[name] for p in parts]), full[name]), name
     for name in ("reward", "done"):
@@ -49,7 +52,7 @@ def test_two_ranks_own_their_shards_of_the_gpu_outputs(tmp_path, N, G, E, T):
     want = dict(zip(full["summary_keys"].tolist(), full["summary_vals"].tolist()))
     for p in parts:                                            # every rank holds the same global figures
         got = dict(zip(p["summary_keys"].tolist(), p["summary_vals"].tolist()))
-        assert got["world_size"] == 2 and want["world_size"] == 1 and got["episodes"] == want["episodes"] == E
+        assert got["world_size"] == W and want["world_size"] == 1 and got["episodes"] == want["episodes"]
         for k in ("mean_episode_reward", "mean_episode_true_reward", "mean_episode_collisions", "mean_episode_len",
                   "mean_reward", "agent_steps"):
             assert got[k] == pytest.approx(want[k], rel=1e-12), k
