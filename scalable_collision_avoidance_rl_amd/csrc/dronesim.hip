@@ -145,6 +145,7 @@ template <int K> struct NbrList<K, false> {
         for (int s = 0; s <= K; ++s) key[s] = ~0ull;
         key[0] = nbr_key(dii, agent);
     }
+    template <bool DEFER = false>
     __device__ __forceinline__ void insert(float d, int j, float) { nbr_insert<K>(key, nbr_key(d, j)); }
     __device__ __forceinline__ unsigned index(int kth) const { return (unsigned)key[kth]; }
 };
@@ -157,9 +158,16 @@ template <int K> struct NbrList<K, true> {
         for (int s = 0; s <= K; ++s) { d[s] = __builtin_inff(); j[s] = ~0u; }
         d[0] = dii; j[0] = (unsigned)agent;
     }
+    // DEFER: the caller re-runs the whole walk with DEFER = false when `deg` comes back non-zero (a partner that can
+    // precede the agent itself was seen) -- the hot loop then holds the 5-instruction stages only, with no second path
+    // merging into it (the merge cost 6 register copies and two scalar branches per visited partner)
+    bool deg = false;                                        // per lane; the wave's verdict is a ballot after the walk
+    template <bool DEFER = false>
     __device__ __forceinline__ void insert(float dn, int jn, float dii)
     {
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dn > dii)) != 0ull, 0)) {
+        if (DEFER) {
+            deg |= !(dn > dii);
+        } else if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(dn > dii)) != 0ull, 0)) {
             // general insertion on (d, j) keys over all K+1 entries (NaN distances order like their bit patterns)
             unsigned long long key = nbr_key(dn, jn);
 #pragma unroll
@@ -190,6 +198,18 @@ template <int K> struct NbrList<K, true> {
     }
     __device__ __forceinline__ unsigned index(int kth) const { return j[kth]; }
 };
+
+struct Defer { static constexpr bool value = true; };
+struct NoDefer { static constexpr bool value = false; };
+struct UniArgs { static constexpr bool value = true; };
+struct UniRuntime { static constexpr bool value = false; };
+template <int K> __device__ __forceinline__ bool list_degenerate(NbrList<K, true> &l)
+{
+    const bool d = __builtin_amdgcn_ballot_w64(l.deg) != 0ull;
+    l.deg = false;
+    return d;
+}
+template <int K> __device__ __forceinline__ bool list_degenerate(NbrList<K, false> &) { return false; }
 
 // @phase h_nan_to_num
 __device__ __forceinline__ float nan_to_num_f32(float x)   // np.nan_to_num, drone_env.py:287-288
@@ -351,16 +371,24 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // Every wave covers a CONTIGUOUS range of global agents [wga0, wga0 + nval): lane l <-> agent wga0 + l.
     // wga0 / nval are wave-uniform (SGPRs), so every per-agent array is addressed as uniform base + lane.
     int slot, agent, env0, nval;
+    // XCD-aware workgroup -> env mapping.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with its own L2;
+    // with env = workgroup id the 128-byte lines of the per-env arrays (t, n_coll: 32 envs per line, done: 128) were
+    // written piecewise by all 8 L2s and left the chip as 8 partial write-backs at the end of the launch.  Every XCD
+    // now owns runs of 32 consecutive virtual workgroups (128 envs at N = 64): whole lines per L2 (-0.11 us per launch at C3).
+    unsigned vb = blockIdx.x;
+#if !defined(DRONESIM_NO_XCD_MAP)
+    if (vb < (gridDim.x & ~255u)) vb = ((vb >> 8) << 8) + ((vb & 7u) << 5) + ((vb >> 3) & 31u);
+#endif
     if (WL) {                                                // lane -> (env slot inside the wave, agent)
         const int sub = SYM ? 0 : (int)lane / N;
         slot = wave * a.P + sub;
         agent = (int)lane - sub * N;
-        env0 = blockIdx.x * a.epb + wave * a.P;
+        env0 = (int)vb * a.epb + wave * a.P;
         nval = max(0, min(a.P, a.E - env0)) * N;
     } else {
         slot = 0;
         agent = tid;
-        env0 = blockIdx.x;
+        env0 = (int)vb;
         nval = max(0, min(kWave, N - wave * kWave));
     }
     const size_t wga0 = (size_t)env0 * N + (WL ? 0 : wave * kWave);
@@ -595,10 +623,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 
         // @phase pass2_visit
         // pass 2 body: the pair (this agent, partner at index jdup of the doubled position array)
-        auto visit = [&](int jdup) {
+        auto visit = [&](int jdup, auto defer, auto uni) {
             const float2 pj = spos_env[jdup];
             const int j = jdup - ((jdup >= N) ? N : 0);
-            const float2 cj = uni_args ? make_float2(a.delta_u, a.radius_u) : sconst[j];   // (Delta_j, l_j)
+            // (Delta_j, l_j): `uni` = known at the call site to be the kernel-argument scalars (the hot walk is written
+            // out once per case: a run-time choice inside the loop costs two register copies and a branch per partner)
+            const float2 cj = (decltype(uni)::value || uni_args) ? make_float2(a.delta_u, a.radius_u) : sconst[j];
             const float dx = xi - pj.x, dy = yi - pj.y;
             const float d2 = fmaf(dy, dy, dx * dx);
             if (CACHED && !(d2 < thr)) return;                                // listed but currently far
@@ -607,7 +637,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             s_msk += pt.inm ? pt.lg : 0.0f;                                   // :282
             ncoll += pt.coll ? 1 : 0;                                         // :284
             in_range += pt.inm ? 1 : 0;
-            list.insert(pt.d, j, dii);                                        // :338
+            list.template insert<decltype(defer)::value>(pt.d, j, dii);      // :338
         };
 
         // @phase filter_generic2
@@ -676,7 +706,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     while (hits) {
                         const int u = __builtin_ctzll(hits);
                         hits &= hits - 1ull;
-                        visit(64 * w + u);
+                        visit(64 * w + u, NoDefer{}, UniRuntime{});
                     }
                 }
             }
@@ -802,10 +832,40 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #if defined(DRONESIM_ABLATE_PASS2)
                 s_all += (float)__builtin_popcountll(near); near = 0ull;
 #endif
+                if (SYM) {
+                    // hot walk with the deferred neighbour list; a wave that met a partner at or inside its agent's own
+                    // entry (coincident agents, a larger partner over a smaller agent's centre) starts over with the
+                    // general insertion, out of line
+                    const unsigned long long near0 = near;
+                    if (uni_args) {
+                        while (near) {
+                            const int u = __builtin_ctzll(near);
+                            near &= near - 1ull;
+                            visit(u, Defer{}, UniArgs{});
+                        }
+                    } else {
+                        while (near) {
+                            const int u = __builtin_ctzll(near);
+                            near &= near - 1ull;
+                            visit(u, Defer{}, UniRuntime{});
+                        }
+                    }
+                    if (__builtin_expect(list_degenerate(list), 0)) {
+                        list.init(dii, agent);
+                        in_range = ((dii <= delta_i) ? 1 : 0) - 1;
+                        s_all = 0.f; s_msk = 0.f; ncoll = 0;
+                        near = near0;
+                        while (near) {
+                            const int u = __builtin_ctzll(near);
+                            near &= near - 1ull;
+                            visit(u, NoDefer{}, UniRuntime{});
+                        }
+                    }
+                } else
                 while (near) {
                     const int u = __builtin_ctzll(near);
                     near &= near - 1ull;
-                    visit(SYM ? u : agent + r0 + u);
+                    visit(agent + r0 + u, NoDefer{}, UniRuntime{});
                 }
             }
         }
@@ -824,7 +884,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             tr_out = -nan_to_num_f32(fmaf(a.b, s_all, to_goal));
             if (a.reward) st_out(a.reward + so + wga0 + lane, r_out);
             if (a.true_reward) st_out(a.true_reward + so + wga0 + lane, tr_out);
+#if defined(DRONESIM_ABL_NOSUM)
+            if (false) {
+#else
             if (SYM && has_acc) {                             // all 64 lanes are here (one env per wave): start the
+#endif
                 const float2 sm = wave_sum64_pair(r_out, tr_out);   // dependent chain now, the rows below overlap it
                 r_env = sm.x; tr_env = sm.y;
             }
@@ -1090,7 +1154,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                             while (m) {                           // ascending order, like every other path
                                 const int u = __builtin_ctzll(m);
                                 m &= m - 1ull;
-                                visit(64 * w + u);
+                                visit(64 * w + u, NoDefer{}, UniRuntime{});
                             }
                         }
                     } else {
@@ -1102,7 +1166,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                                 const float dx = xi - pj.x, dy = yi - pj.y;
                                 if (!(fmaf(dy, dy, dx * dx) < thr)) continue;
                             }
-                            visit(j);
+                            visit(j, NoDefer{}, UniRuntime{});
                         }
                     }
                     const float zx = (xi - xFx) - xLx, zy = (yi - xFy) - xLy;
