@@ -351,6 +351,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // for the kernel-argument fetch ahead of the first pos / act loads
     const int epi_flags = EPI ? (epb >> 16) : 0;
     if (EPI) epb &= 0xffff;
+    const unsigned xcd_blocks = (unsigned)P & ~255u;         // workgroups in whole groups of 256 (XCD map below)
+    P &= 255;
     a.pos = pos; a.P = P; a.epb = epb; a.E = E; a.N = n_agents;
     if (MODE == kObserve) a.vel = const_cast<float *>(vel_or_act); else a.act = vel_or_act;
     constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
@@ -375,9 +377,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // with env = workgroup id the 128-byte lines of the per-env arrays (t, n_coll: 32 envs per line, done: 128) were
     // written piecewise by all 8 L2s and left the chip as 8 partial write-backs at the end of the launch.  Every XCD
     // now owns runs of 32 consecutive virtual workgroups (128 envs at N = 64): whole lines per L2 (-0.11 us per launch at C3).
+    // (the number of workgroups in whole groups of 256 travels in the high bits of the preloaded `P` argument: reading
+    // gridDim would put a scalar fetch and its wait ahead of the first state loads)
     unsigned vb = blockIdx.x;
 #if !defined(DRONESIM_NO_XCD_MAP)
-    if (vb < (gridDim.x & ~255u)) vb = ((vb >> 8) << 8) + ((vb & 7u) << 5) + ((vb >> 3) & 31u);
+    if (vb < xcd_blocks) vb = ((vb >> 8) << 8) + ((vb & 7u) << 5) + ((vb >> 3) & 31u);
 #endif
     if (WL) {                                                // lane -> (env slot inside the wave, agent)
         const int sub = SYM ? 0 : (int)lane / N;
@@ -995,6 +999,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #endif
             unsigned *gz = reinterpret_cast<unsigned *>(a.z) + (so + wga0) * kZRow;
             unsigned *gn = reinterpret_cast<unsigned *>(a.nbr_idx) + (so + wga0) * kNRow;
+            // wave-uniform row bases: pinned in SGPRs so that the stores below address as scalar base + 32-bit lane
+            // offset (the compiler otherwise builds 64-bit per-lane addresses: three v_lshl_add_u64 and two v_mad_i64_i32)
+            typedef __attribute__((address_space(1))) u32x4 gu32x4;   // (the asm would otherwise leave generic pointers)
+            gu32x4 *gz4 = (gu32x4 *)gz, *gn4 = (gu32x4 *)gn;
+            if (SYM) asm volatile("" : "+s"(gz4), "+s"(gn4));
             if (SYM) {
                 // full wave of one env, 16-byte aligned rows (checked on the host): fixed-shape copy, no loops
                 // (a branch-free variant -- surplus lanes of a ragged last round repeating a live lane's 16 bytes, so
@@ -1003,11 +1012,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #pragma unroll
                 for (int o = 0; o < nz; o += 4 * kWave)
                     if (o + 4 * kWave <= nz || (int)lane * 4 < nz - o)
-                        st_out(reinterpret_cast<u32x4 *>(gz + o) + lane, reinterpret_cast<const u32x4 *>(stage_z + o)[lane]);
+                        __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(stage_z + o)[lane], gz4 + o / 4 + lane);
 #pragma unroll
                 for (int o = 0; o < nn; o += 4 * kWave)
                     if (o + 4 * kWave <= nn || (int)lane * 4 < nn - o)
-                        st_out(reinterpret_cast<u32x4 *>(gn + o) + lane, reinterpret_cast<const u32x4 *>(stage_n + o)[lane]);
+                        __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(stage_n + o)[lane], gn4 + o / 4 + lane);
             } else {
                 wave_copy_out(gz, stage_z, nval * kZRow, lane);
                 wave_copy_out(gn, stage_n, nval * kNRow, lane);
@@ -1663,7 +1672,8 @@ hipError_t launch_one(const KArgs &a, const Geometry &g, hipStream_t s)
         }
     }
     hipLaunchKernelGGL((drone_kernel<K, FAR, MODE, GEO, EPI>), dim3(g.blocks), dim3(g.threads), g.lds, s,
-                       a.pos, MODE == kObserve ? static_cast<const float *>(a.vel) : a.act, a.P,
+                       a.pos, MODE == kObserve ? static_cast<const float *>(a.vel) : a.act,
+                       (int)((unsigned)a.P | ((unsigned)g.blocks & ~255u)),   // P <= 64; whole groups of 256 workgroups (XCD map)
                        EPI ? (a.epb | ((a.acc != nullptr ? 1 : 0) | (a.auto_reset ? 2 : 0) | (a.rand_act ? 4 : 0)) << 16) : a.epb,
                        a.E, a.N, a);
     return hipSuccess;
