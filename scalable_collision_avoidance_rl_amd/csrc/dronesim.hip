@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
     const bool uni_args = MODE != kRollout && a.uniform != 0;
     if (WL) {
-        if ((int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;
+        if (!SYM && (int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;   // kSym64 keeps these verdicts in scalar registers
         if (!uni_args && (int)lane < N)
             sconst[lane] = a.uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[lane], a.radius[lane]);
     } else {
@@ -876,6 +876,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         // @phase epilogue_rewards_z
         float r_out = 0.0f, tr_out = 0.0f;                    // this lane's rewards (episode bookkeeping)
         float r_env = 0.0f, tr_env = 0.0f;                    // their sums over the env, valid in its agent-0 lane
+        int coll_s = 0;                                       // kSym64: the env's collisions / agents outside the goal
+        unsigned long long outside_m = 0ull;                  //         disk, wave-uniform (scalar registers)
         if (valid) {
             TRACE_MARK(3);
             // rewards (:276, :287-288)
@@ -957,9 +959,18 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #endif
                     st_out2(a.vel + 2 * wga0 + 2 * lane, vxi, vyi);
                 }
-                if (!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius)) atomicOr(&sred[2 * slot + 1], 1);   // :249-251
+                if (SYM) outside_m = __builtin_amdgcn_ballot_w64(!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius));
+                else if (!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius)) atomicOr(&sred[2 * slot + 1], 1);   // :249-251
             }
-            if (ncoll) atomicAdd(&sred[2 * slot], ncoll);
+            if (SYM) {
+                // one env per wave: the env's collision count is a sum of ballot popcounts on the scalar unit (ballots of
+                // ncoll >= 1, >= 2, ...: one or two rounds), the arrival verdict one ballot -- no LDS words, no waits
+                unsigned long long m = __builtin_amdgcn_ballot_w64(ncoll > 0);
+                for (int lvl = 1; m != 0ull; ++lvl) {
+                    coll_s += __builtin_popcountll(m);
+                    m = __builtin_amdgcn_ballot_w64(ncoll > lvl);
+                }
+            } else if (ncoll) atomicAdd(&sred[2 * slot], ncoll);
         }
         // episode bookkeeping: sum of this step's rewards per env, fixed order (bit-reproducible).  Workgroup-per-env
         // geometries leave one partial per wave in LDS ahead of the barrier below; wave-local geometries reduce after
@@ -1024,6 +1035,26 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         }
         // @phase env_outputs
         bool fin_env = false;                                 // agent 0: this env's episode ended with this step
+        if (SYM) {
+            // one env per wave: verdicts are wave-uniform, the record update is branch-free (lane 0 holds the two sums,
+            // lane 1 the counters), and lane 0's stores are the only masked region
+            const int tc = MODE != kObserve ? __builtin_amdgcn_readfirstlane(tcur) : 0;      // lane 0 = agent 0
+            const bool fin = MODE != kObserve && (outside_m == 0ull || tc >= a.max_steps - 1);   // :251
+            fin_env = fin;
+            if (has_acc) {                                        // train_problem.py:98-100 and t_iter, every step
+                const double nr = __builtin_bit_cast(double, make_uint2(accw.x, accw.y)) + (double)r_env;
+                const double ntr = __builtin_bit_cast(double, make_uint2(accw.z, accw.w)) + (double)tr_env;
+                const uint2 w0 = __builtin_bit_cast(uint2, nr), w1 = __builtin_bit_cast(uint2, ntr);
+                const bool l0 = lane == 0;
+                accw = make_uint4(l0 ? w0.x : accw.x + (unsigned)coll_s, l0 ? w0.y : accw.y + 1u,
+                                  l0 ? w1.x : accw.z, l0 ? w1.y : accw.w);
+            }
+            if (lane == 0) {
+                const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
+                if (a.n_coll) a.n_coll[eo] = coll_s;
+                if (MODE != kObserve) a.done[eo] = (uint8_t)fin;
+            }
+        } else
         if (valid && (agent == 0 || (has_acc && agent == 1))) {
             const int2 red = *reinterpret_cast<const int2 *>(sred + 2 * slot);   // (collisions, someone outside the goal disk)
             const int coll_env = red.x;
