@@ -905,17 +905,21 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             zrx[0] = zx; zry[0] = zy; nbv[0] = agent;
             bool have[K + 1];
             have[0] = true;
+            // all K neighbour positions are requested before the first is used (one LDS round trip instead of K; an
+            // entry without a neighbour reads the agent's own slot and is discarded)
+            float2 pnb[K + 1];
 #pragma unroll
             for (int kth = 1; kth <= K; ++kth) {
                 const unsigned j = list.index(kth);
                 have[kth] = j < (unsigned)N;
+                pnb[kth] = spos_env[have[kth] ? j : (unsigned)agent];
+            }
+#pragma unroll
+            for (int kth = 1; kth <= K; ++kth) {
+                const unsigned j = list.index(kth);
                 const bool real = kth <= in_range && have[kth];               // :362
-                float rx = ghx, ry = ghy;
-                if (real) {
-                    const float2 pj = spos_env[j];
-                    rx = pj.x - xi; ry = pj.y - yi;                           // :368
-                }
-                zrx[kth] = rx; zry[kth] = ry;
+                zrx[kth] = real ? pnb[kth].x - xi : ghx;                      // :368
+                zry[kth] = real ? pnb[kth].y - yi : ghy;
                 nbv[kth] = real ? (int)j : -1;
             }
             if (!staged) {                                                    // c = 5 rows / masked observe
@@ -1019,15 +1023,24 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 // full wave of one env, 16-byte aligned rows (checked on the host): fixed-shape copy, no loops
                 // (a branch-free variant -- surplus lanes of a ragged last round repeating a live lane's 16 bytes, so
                 // that the kernel's tail is one basic block -- was 0.14 us slower per launch: the stores got wider)
+                // All staged words are read before the first store is issued (one LDS round trip for the whole copy-out;
+                // the surplus lanes of a ragged last round read on into the next wave's staging area or the bucket tables
+                // behind it -- at least 4 KiB, allocated in every kSym64 launch -- and store nothing).
                 constexpr int nz = kWave * kZRow, nn = kWave * kNRow;          // words
+                constexpr int rz = (nz + 4 * kWave - 1) / (4 * kWave), rn = (nn + 4 * kWave - 1) / (4 * kWave);
+                u32x4 vz[rz], vn[rn];
 #pragma unroll
-                for (int o = 0; o < nz; o += 4 * kWave)
-                    if (o + 4 * kWave <= nz || (int)lane * 4 < nz - o)
-                        __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(stage_z + o)[lane], gz4 + o / 4 + lane);
+                for (int r = 0; r < rz; ++r) vz[r] = reinterpret_cast<const u32x4 *>(stage_z + r * 4 * kWave)[lane];
 #pragma unroll
-                for (int o = 0; o < nn; o += 4 * kWave)
-                    if (o + 4 * kWave <= nn || (int)lane * 4 < nn - o)
-                        __builtin_nontemporal_store(reinterpret_cast<const u32x4 *>(stage_n + o)[lane], gn4 + o / 4 + lane);
+                for (int r = 0; r < rn; ++r) vn[r] = reinterpret_cast<const u32x4 *>(stage_n + r * 4 * kWave)[lane];
+#pragma unroll
+                for (int r = 0; r < rz; ++r)
+                    if ((r + 1) * 4 * kWave <= nz || (int)lane * 4 < nz - r * 4 * kWave)
+                        __builtin_nontemporal_store(vz[r], gz4 + r * kWave + lane);
+#pragma unroll
+                for (int r = 0; r < rn; ++r)
+                    if ((r + 1) * 4 * kWave <= nn || (int)lane * 4 < nn - r * 4 * kWave)
+                        __builtin_nontemporal_store(vn[r], gn4 + r * kWave + lane);
             } else {
                 wave_copy_out(gz, stage_z, nval * kZRow, lane);
                 wave_copy_out(gn, stage_n, nval * kNRow, lane);
