@@ -10,11 +10,11 @@ envs whose episode ends (200 steps, drone_env.py:30) reset + re-observed inside 
 pre-generated and resident in HBM before the timed region.
 
 Timing: the K requested steps are captured as ONE hipGraph (whatever K is; a short request several times
-over, ~1000 launches per graph, because a replay costs ~10 us of GPU idle time whatever it holds) and the
+over, ~4000 launches per graph, because a replay costs 0.1-0.3 ms of GPU idle time whatever it holds) and the
 timed region replays that graph `repeats` times -- enough for >= 0.5 s -- between the two barriers, so a
 short `--steps 20` run measures the same thing as a long one: value = N * E * timed_steps / elapsed and
-ms_per_step = elapsed / timed_steps, timed_steps = K * graph_copies * repeats.  Every ~200 steps the path's only exchange runs inside the
-timed region: one fixed-order reduction of the per-env episode records + one all-gather (RCCL).
+ms_per_step = elapsed / timed_steps, timed_steps = K * graph_copies * repeats.  After every replay (every ~200
+steps when a replay is shorter than an episode) the path's only exchange runs inside the timed region: one fixed-order reduction of the per-env episode records + one all-gather (RCCL).
 
 Default workload = BASELINE.json configs[2] (N=64 x E=4096 per GPU, Delta=1.0, G=28): the
 configuration the headline target (>= 1e7 agent-steps/s on 1 GPU) is quoted on; weak scaling:
@@ -219,10 +219,11 @@ def main():
             while step_no % T_ep:                   # plain path resets by step index: align the capture to an episode
                 one_step(step_no); step_no += 1
         torch.cuda.synchronize()
-        # a replay costs ~10 us of GPU idle time whatever the graph holds: a short request is captured several times
-        # over into ONE graph of ~1000 launches (the episode layer keeps every counter on the device, so the copies
-        # simply continue the rollout), and the per-step figure of `--steps 20` is that of `--steps 2000`
-        copies = max(1, -(-1000 // K)) if layer else 1
+        # a replay costs ~0.1-0.3 ms of GPU idle time whatever the graph holds (tools/replay_probe.py: 6.01 us per step
+        # with 250 launches per graph, 5.73 with 1000, 5.62 with 4000): the request is captured several times over into
+        # ONE graph of ~4000 launches (the episode layer keeps every counter on the device, so the copies simply
+        # continue the rollout), and the per-step figure of `--steps 20` is that of `--steps 2000`
+        copies = max(1, -(-4000 // K)) if layer else 1
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             for s in range(K * copies):
@@ -270,9 +271,9 @@ def main():
     # ONLY `n_samp` back-to-back step launches, so (t1 - t0) / n_samp is the kernel's duration including the
     # ~0.2 us dependent-launch boundary and excluding host launch latency.  rocprofv3 --kernel-trace --stats
     # of this command reports the same kernel's average duration (profiles/).
-    # With the episode layer the graph holds five episodes (the in-kernel resets fire inside it, as in the timed
-    # region); the ~10-16 us a graph replay costs on the host side is then < 0.3 % of the bracketed time.
-    n_samp = 5 * T_ep if layer else T_ep
+    # With the episode layer the graph holds twenty episodes (the in-kernel resets fire inside it, as in the timed
+    # region); the ~0.1 ms a graph replay costs is then < 0.5 % of the bracketed time.
+    n_samp = 20 * T_ep if layer else T_ep
     kgraph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(kgraph):
         for s in range(n_samp):

@@ -1011,6 +1011,29 @@ def test_invariances(torch):
     assert float((barrier(full) - barrier(moved)).abs().max()) < 2e-3     # cancellation of two O(30) terms in f32
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,epb", [(64, 4), (256, 1), (20, 12)])
+def test_workgroup_to_env_mapping_is_transparent(torch, N, epb):
+    """The step kernel hands runs of 32 consecutive workgroups' envs to one XCD (whole groups of 256 workgroups are
+    permuted, the ragged rest is not).  Which workgroup steps which env must not show: launches of 255 / 256 / 257 /
+    513 / 1030 workgroups agree bit for bit with the same envs stepped as part of another batch, including the
+    per-env outputs and the episode records."""
+    G = 28.0 if N <= 64 else 64.0
+    Emax = 1030 * epb
+    rng = np.random.default_rng(N)
+    pos = (G * rng.random((Emax, N, 2))).astype(np.float32)
+    act = torch.tensor(rng.uniform(-1, 1, (Emax, N, 2)).astype(np.float32), device="cuda:0")
+    full = make_env(N, G, 2, 2, np.ones(N), Emax, track_episodes=True)
+    full.set_state(pos); full.step(act); full.step(act)
+    for blocks in (255, 256, 257, 513):
+        E = blocks * epb - (1 if blocks == 257 else 0)                    # one ragged last workgroup as well
+        part = make_env(N, G, 2, 2, np.ones(N), E, track_episodes=True)
+        part.set_state(pos[:E]); part.step(act[:E]); part.step(act[:E])
+        for name in ("reward", "true_reward", "z", "nbr_idx", "n_coll", "done", "pos", "vel", "t"):
+            assert torch.equal(getattr(part, name), getattr(full, name)[:E]), (blocks, name)
+        assert torch.equal(part.episode_acc, full.episode_acc[:E]), blocks
+
+
 def formation_xF(N, G):
     from scalable_collision_avoidance_rl_amd import formation_O
     return formation_O(N, [G, G])[0].reshape(N, 2).astype(np.float32)
