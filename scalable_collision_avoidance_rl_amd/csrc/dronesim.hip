@@ -440,11 +440,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         // (measured: -0.1 us at C3; the workgroup-per-env shapes at BASELINE size -- C5 shard, 2 MB of state --
         // are 0.2 us faster with plain loads, and a run-time choice costs more than either)
         float2 p;
-#if defined(DRONESIM_POS_PLAIN)
-        if (true) {
-#else
         if (BLOCKGEO) {
-#endif
             p = pos_in[lane];
         } else {
             const f32x2 pl = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(pos_in) + lane);
@@ -956,11 +952,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             // @phase epilogue_state_done
             if (MODE != kObserve) {
                 if (MODE != kRollout || step == nsteps - 1) {                 // final state only
-#if defined(DRONESIM_POS_PLAIN)
-                    *reinterpret_cast<float2 *>(a.pos + 2 * wga0 + 2 * lane) = make_float2(xi, yi);
-#else
                     st_out2(a.pos + 2 * wga0 + 2 * lane, xi, yi);
-#endif
                     st_out2(a.vel + 2 * wga0 + 2 * lane, vxi, vyi);
                 }
                 if (SYM) outside_m = __builtin_amdgcn_ballot_w64(!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius));

@@ -9,6 +9,7 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 T="timeout 280"
+[ -f tools/libcalib.so ] || make -C tools libcalib.so   # PMC calibration copies (pmc_run.py)
 $T python bench.py --steps 2000 --warmup 200 > $OUT/${TAG}_c3_bench.json 2> $OUT/${TAG}_c3_bench.err
 tail -1 $OUT/${TAG}_c3_bench.json | cut -c1-400
 $T python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_c3_bench_steps20.json 2>> $OUT/${TAG}_c3_bench.err
