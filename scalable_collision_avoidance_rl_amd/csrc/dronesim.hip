@@ -12,7 +12,7 @@
 //
 // Work decomposition (one launch = one env.step() for E envs); DESIGN.md section 3 has the measurements
 //   N <= 64 : lane = agent; floor(64/N) envs packed per wave, 4 independent waves per 256-thread
-//             workgroup, wave-local synchronisation only.  N = 64 -> one wave per env.
+//             workgroup (2 per 128-thread workgroup when a wave holds one env), wave-local synchronisation only.  N = 64 -> one wave per env.
 //   N  > 64 : one workgroup per env, thread = agent (N <= 1024).
 //   Every wave covers a contiguous range of global agents: streams are wave-uniform base + lane.
 //   LDS tile: the integrated positions of an env, read by agent index.
@@ -306,7 +306,7 @@ constexpr uint32_t kRandActKey = 0x52414E44u;   // "RAND": separates the action 
 
 // @phase h_misc
 // Workgroup geometries
-//   kPacked  : N <= 64.  256 threads = 4 independent waves; each wave holds floor(64/N) whole envs and
+//   kPacked  : N <= 64.  256 (N > 32: 128) threads = 4 (2) independent waves; each wave holds floor(64/N) whole envs and
 //              touches only its own LDS, so all synchronisation is wave-local (no s_barrier).
 //   kSym64   : kPacked specialised for N == 64 without far agents: every unordered pair is evaluated
 //              ONCE (lane i tests partners i+1..i+32; the verdict reaches the partner as a rotated
@@ -315,7 +315,11 @@ constexpr uint32_t kRandActKey = 0x52414E44u;   // "RAND": separates the action 
 enum Geo { kPacked = 0, kSym64 = 1, kBlock256 = 2, kBlock1024 = 3 };
 
 template <int GEO> struct GeoTraits {
+#if defined(DRONESIM_WG_THREADS)      // developer experiment: waves per workgroup of the wave-local geometries
+    static constexpr int kMaxThreads = GEO == kBlock1024 ? 1024 : (DRONESIM_WG_THREADS > 256 ? DRONESIM_WG_THREADS : 256);
+#else
     static constexpr int kMaxThreads = GEO == kBlock1024 ? 1024 : 256;
+#endif
     // C3 needs 4 resident waves per SIMD (4096 envs = 4096 waves on 1024 SIMDs): cap the register budget at 128
     static constexpr int kMinWavesPerSimd = GEO == kBlock1024 ? 1 : 4;
     static constexpr bool kWaveLocal = GEO == kPacked || GEO == kSym64;
@@ -1617,10 +1621,19 @@ struct Geometry {
 Geometry geometry(int N, int E)
 {
     Geometry g;
-    if (N <= kWave) {                  // 4 independent waves per workgroup, floor(64/N) envs per wave
+    if (N <= kWave) {                  // 4 (or 2) independent waves per workgroup, floor(64/N) envs per wave
         g.P = kWave / N;
-        g.threads = 256;
-        g.epb = 4 * g.P;
+#if defined(DRONESIM_WG_THREADS)
+        g.threads = DRONESIM_WG_THREADS;
+        g.epb = (DRONESIM_WG_THREADS / 64) * g.P;
+#else
+        // one env per wave (N > 32): two waves per workgroup -- measured against 4 (the round-1 choice), 8 and 16 at C3:
+        // 5.33 / 5.40 / 5.42 / 5.71 us per launch (a single wave per workgroup doubles the cost of an empty launch);
+        // several small envs per wave keep 4 (C2: 3.85 us against 4.13 with 2)
+        const int wpb = g.P == 1 ? 2 : 4;
+        g.threads = wpb * kWave;
+        g.epb = wpb * g.P;
+#endif
         g.geo = kPacked;
     } else {
         g.P = 0;
