@@ -757,6 +757,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     unsigned long long hits = 0ull;          // bit j: agent j is inside the list radius
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_popcountll(pool) > kBucketMax) == 0ull, 1)) {
                         // (b) exact test of the few candidates
+                        // (requesting 2 or 4 candidates' positions per LDS round trip was measured: +0.04 / +0.08 us per launch --
+                        // this part of a wave is issue-bound, the other three waves of the SIMD cover the round trips)
                         while (pool) {
                             const int j = __builtin_ctzll(pool);
                             pool &= pool - 1ull;
