@@ -1456,56 +1456,134 @@ __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
 // kStageT time steps are requested together before the sequential recurrence consumes them.
 constexpr int kStageT = 8;
 
+// done[t][e] for the eight time steps t_of(0..7) of a stage, fetched by the WAVE with one load instruction instead of
+// eight per thread: lane 8 k + u reads the flag of (step u, k-th env the wave touches), every thread then picks its
+// env's flags with a lane permute.  (One 1-byte load per thread and step -- all lanes of a wave on the same address --
+// made the returns scan 2x slower than a copy of the same size: 147 us against 74 without the flags at T = 200 x C3.)
+// Valid when the wave's columns span at most 8 envs (`coop`, wave-uniform); otherwise threads read their own flags.
+struct DoneStage {
+    unsigned v;
+    template <typename TOf>
+    __device__ __forceinline__ void fetch(const uint8_t *done, size_t e_first, int E, int T, TOf t_of)
+    {
+        const int lane = threadIdx.x & 63, k = lane >> 3, u = lane & 7;
+        const int t = t_of(u);
+        v = (t >= 0 && t < T && e_first + k < (size_t)E) ? done[(size_t)t * E + e_first + k] : 0u;
+    }
+    __device__ __forceinline__ bool get(int de, int u) const { return __shfl((int)v, 8 * de + u, 64) != 0; }
+};
+
 __global__ void __launch_bounds__(256) returns_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done,
                                                       float gamma, float *__restrict__ G, int T, int E, int N)
 {
-    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t EN = (size_t)E * N;
-    if (col >= EN) return;
+    const size_t col0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = col0 < EN;                               // (no early exit: the flag fetch is a wave operation)
+    const size_t col = act ? col0 : EN - 1;
     const size_t e = col / N;
+    const size_t e_first = (size_t)__shfl((long long)e, 0, 64);
+    const int de = (int)(e - e_first);
+    const bool coop = done != nullptr && __builtin_amdgcn_ballot_w64(de >= 8) == 0ull;
     float g = 0.0f;
     for (int t0 = T - 1; t0 >= 0; t0 -= kStageT) {
         float r[kStageT];
         bool last[kStageT];
+        DoneStage ds;
+        if (coop) ds.fetch(done, e_first, E, T, [&](int u) { return t0 - u; });
 #pragma unroll
         for (int u = 0; u < kStageT; ++u) {
             const int t = t0 - u;
             r[u] = t >= 0 ? __builtin_nontemporal_load(reward + (size_t)t * EN + col) : 0.0f;
-            last[u] = t == T - 1 || (done != nullptr && t >= 0 && done[(size_t)t * E + e] != 0);
+            if (!coop) last[u] = t == T - 1 || (done != nullptr && t >= 0 && done[(size_t)t * E + e] != 0);
+        }
+        if (coop) {
+#pragma unroll
+            for (int u = 0; u < kStageT; ++u) last[u] = t0 - u == T - 1 || ds.get(de, u);
         }
 #pragma unroll
         for (int u = 0; u < kStageT; ++u) {
             const int t = t0 - u;
             if (t >= 0) {
                 g = last[u] ? r[u] : fmaf(g, gamma, r[u]);     // :306  Gt[t] = Gt[t+1]*discount + r[t]
-                __builtin_nontemporal_store(g, G + (size_t)t * EN + col);
+                if (act) __builtin_nontemporal_store(g, G + (size_t)t * EN + col);
             }
         }
     }
 }
 
+// K1C = K + 1 at compile time (3 for the reference's k_closest = 2: the neighbour triple is one 12-byte load), 0 = any
+// K1 at run time.  A stage of eight steps requests V and the neighbour ids of all eight first, then the G values they
+// name (slot 0 is the agent itself: a coalesced row read; the others fall into the same 4 N-byte row), then folds.
+template <int K1C>
 __global__ void __launch_bounds__(256) advantage_kernel(const float *__restrict__ G, const float *__restrict__ V,
                                                         const int *__restrict__ nbr, const uint8_t *__restrict__ done,
                                                         float gamma, float *__restrict__ w, int T, int E, int N, int K1)
 {
-    const size_t col = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t EN = (size_t)E * N;
-    if (col >= EN) return;
+    const size_t col0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = col0 < EN;
+    const size_t col = act ? col0 : EN - 1;
     const size_t e = col / N;
+    const size_t e_first = (size_t)__shfl((long long)e, 0, 64);
+    const int de = (int)(e - e_first);
+    const bool coop = done != nullptr && __builtin_amdgcn_ballot_w64(de >= 8) == 0ull;
     double disc = 1.0;                                         // gamma^t kept in double: 200 products stay exact to f32
     const float inv_n = 1.0f / (float)N;
-    for (int t = 0; t < T; ++t) {
-        const size_t o = (size_t)t * EN + col;
-        const float v = V[o];
-        const int *nb = nbr + o * K1;
-        const float *Grow = G + (size_t)t * EN + e * N;
-        float adv = 0.0f;
-        for (int s = 0; s < K1; ++s) {
-            const int j = nb[s];
-            if (j >= 0) adv += Grow[j] - v;                   // :345-346  (i itself is slot 0)
+    for (int t0 = 0; t0 < T; t0 += kStageT) {
+        DoneStage ds;
+        if (coop) ds.fetch(done, e_first, E, T, [&](int u) { return t0 + u; });
+        if (K1C > 0) {
+            float v[kStageT], adv[kStageT];
+            int j[kStageT][K1C > 0 ? K1C : 1];
+#pragma unroll
+            for (int u = 0; u < kStageT; ++u) {
+                const int t = min(t0 + u, T - 1);
+                const size_t o = (size_t)t * EN + col;
+                v[u] = __builtin_nontemporal_load(V + o);
+#pragma unroll
+                for (int q = 0; q < K1C; ++q) j[u][q] = __builtin_nontemporal_load(nbr + o * K1C + q);
+            }
+#pragma unroll
+            for (int u = 0; u < kStageT; ++u) {
+                const int t = min(t0 + u, T - 1);
+                const float *Grow = G + (size_t)t * EN + e * N;
+                float a = 0.0f;
+#pragma unroll
+                for (int q = 0; q < K1C; ++q) {
+                    const float gq = Grow[j[u][q] >= 0 ? j[u][q] : 0];
+                    a += j[u][q] >= 0 ? gq - v[u] : 0.0f;      // :345-346  (i itself is slot 0)
+                }
+                adv[u] = a;
+            }
+#pragma unroll
+            for (int u = 0; u < kStageT; ++u) {
+                const int t = t0 + u;
+                if (t < T) {
+                    if (act) __builtin_nontemporal_store(inv_n * (float)disc * adv[u], w + (size_t)t * EN + col);   // :351
+                    const bool d = coop ? ds.get(de, u) : (done != nullptr && done[(size_t)t * E + e] != 0);
+                    disc = d ? 1.0 : disc * (double)gamma;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < kStageT; ++u) {
+                const int t = t0 + u;
+                if (t < T) {
+                    const size_t o = (size_t)t * EN + col;
+                    const float v = V[o];
+                    const int *nb = nbr + o * K1;
+                    const float *Grow = G + (size_t)t * EN + e * N;
+                    float adv = 0.0f;
+                    for (int q = 0; q < K1; ++q) {
+                        const int jq = nb[q];
+                        if (jq >= 0) adv += Grow[jq] - v;      // :345-346  (i itself is slot 0)
+                    }
+                    if (act) w[o] = inv_n * (float)disc * adv; // :351
+                    const bool d = coop ? ds.get(de, u) : (done != nullptr && done[(size_t)t * E + e] != 0);
+                    disc = d ? 1.0 : disc * (double)gamma;
+                }
+            }
         }
-        w[o] = inv_n * (float)disc * adv;                      // :351
-        disc = (done != nullptr && done[(size_t)t * E + e] != 0) ? 1.0 : disc * (double)gamma;
     }
 }
 
@@ -2080,8 +2158,12 @@ int dronesim_advantage(const float *G, const float *V, const int32_t *nbr_idx, c
         return fail(DRONESIM_EINVAL, "dronesim_advantage: bad argument");
     if (T == 0 || E == 0) return DRONESIM_OK;
     const size_t cols = (size_t)E * N;
-    hipLaunchKernelGGL(advantage_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       G, V, nbr_idx, done, gamma, w, T, E, N, K1);
+    if (K1 == 3)
+        hipLaunchKernelGGL(advantage_kernel<3>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           G, V, nbr_idx, done, gamma, w, T, E, N, K1);
+    else
+        hipLaunchKernelGGL(advantage_kernel<0>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           G, V, nbr_idx, done, gamma, w, T, E, N, K1);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
