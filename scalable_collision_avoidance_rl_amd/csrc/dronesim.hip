@@ -356,8 +356,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     const int epi_flags = EPI ? (epb >> 16) : 0;
     if (EPI) epb &= 0xffff;
     const unsigned xcd_blocks = (unsigned)P & ~255u;         // workgroups in whole groups of 256 (XCD map below)
-    P &= 255;
-    a.pos = pos; a.P = P; a.epb = epb; a.E = E; a.N = n_agents;
+    a.pos = pos; a.P = P & 255; a.epb = epb; a.E = E; a.N = n_agents;
     if (MODE == kObserve) a.vel = const_cast<float *>(vel_or_act); else a.act = vel_or_act;
     constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
     constexpr bool SYM = GEO == kSym64;
@@ -1016,7 +1015,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             // offset (the compiler otherwise builds 64-bit per-lane addresses: three v_lshl_add_u64 and two v_mad_i64_i32)
             typedef __attribute__((address_space(1))) u32x4 gu32x4;   // (the asm would otherwise leave generic pointers)
             gu32x4 *gz4 = (gu32x4 *)gz, *gn4 = (gu32x4 *)gn;
+#if !defined(DRONESIM_TRACE)                                   // (the trace build's stamps make hipcc lose the uniformity)
             if (SYM) asm volatile("" : "+s"(gz4), "+s"(gn4));
+#endif
             if (SYM) {
                 // full wave of one env, 16-byte aligned rows (checked on the host): fixed-shape copy, no loops
                 // (a branch-free variant -- surplus lanes of a ragged last round repeating a live lane's 16 bytes, so
