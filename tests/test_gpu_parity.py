@@ -747,6 +747,28 @@ def _modules(fx, prefix, names):
     return mods
 
 
+@pytest.mark.parametrize("T,E,N,K1", [(13, 37, 3, 3), (9, 11, 5, 3), (17, 70, 2, 2), (21, 9, 7, 4), (40, 3, 64, 3)])
+def test_learner_scans_done_flag_paths(torch, T, E, N, K1):
+    """The scans fetch the done flags once per wave (up to 8 envs per wave) and fall back to per-thread reads when a
+    wave's columns span more envs (N < 8 with many envs); both against the oracle, with a ragged last wave."""
+    from oracle.oracle import mc_returns as o_ret, neighbour_advantage as o_adv
+    from scalable_collision_avoidance_rl_amd.rollout_buffer import mc_returns, neighbour_advantage
+    rng = np.random.default_rng(T * 1000 + E)
+    r = rng.normal(0, 3, (T, E, N)).astype(np.float32)
+    V = rng.normal(0, 5, (T, E, N)).astype(np.float32)
+    done = (rng.random((T, E)) < 0.15).astype(np.uint8)
+    nbr = rng.integers(0, N, (T, E, N, K1)).astype(np.int32)
+    nbr[rng.random(nbr.shape) < 0.25] = -1
+    nbr[..., 0] = np.arange(N)[None, None]
+    dt = torch.tensor(done, device="cuda:0")
+    G = mc_returns(torch.tensor(r, device="cuda:0"), 0.93, dt)
+    ref_G = o_ret(r, 0.93, done)
+    H.assert_close(host(G), ref_G, "returns", rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_G).max())))
+    w = neighbour_advantage(G, torch.tensor(V, device="cuda:0"), torch.tensor(nbr, device="cuda:0"), 0.93, dt)
+    ref_w = o_adv(host(G).astype(np.float64), V, nbr, 0.93, done)
+    H.assert_close(host(w), ref_w, "advantage", rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref_w).max())))
+
+
 def test_batched_policies_match_reference_networks(torch):
     """DiscreteSoftmaxNN / NormalActorNN / CriticNN forward outputs of the reference's own modules
     (utils.py:14-117, 255-302) reproduced by the batched matrix-core kernel in exact float32."""
