@@ -273,9 +273,11 @@ __device__ __forceinline__ float2 wave_sum64_pair(float a, float b)
     float t = v + dpp_or_zero<0x111, 0xf, 0xf>(v);
     t += dpp_or_zero<0x112, 0xf, 0xf>(v);
     t += dpp_or_zero<0x113, 0xf, 0xf>(v);
-    t += dpp_or_zero<0x114, 0xf, 0xe>(t);
-    t += dpp_or_zero<0x118, 0xf, 0xc>(t);
-    t += dpp_or_zero<0x142, 0xa, 0xf>(t);
+    // the bank- / row-masked stages add in place (lanes outside the mask keep t): one instruction each -- through
+    // update_dpp the compiler spends three (zero the temporary, v_mov_dpp into it, add)
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(t));
     return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 31)),
                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63)));
 }
