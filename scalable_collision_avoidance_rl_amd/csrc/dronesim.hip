@@ -708,12 +708,34 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #if defined(DRONESIM_ABLATE_PASS2)
                     s_all += (float)__builtin_popcountll(hits); hits = 0ull;
 #endif
-                    while (hits) {
-                        const int u = __builtin_ctzll(hits);
-                        hits &= hits - 1ull;
-                        visit(64 * w + u, NoDefer{}, UniRuntime{});
+                    pool[w] = hits;                          // the verdicts replace the candidates
+                }
+            }
+            // pass 2 over the verdicts, ascending agent order.  Workgroup-per-env geometries (ascending-order list):
+            // the hot walk defers the general insertion and is written out for the uniform-(Delta, l) case, like kSym64's
+            auto walk = [&](auto defer, auto uni) {
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) {
+                    if (w < W) {
+                        unsigned long long hits = pool[w];
+                        while (hits) {
+                            const int u = __builtin_ctzll(hits);
+                            hits &= hits - 1ull;
+                            visit(64 * w + u, defer, uni);
+                        }
                     }
                 }
+            };
+            if (ASC) {
+                if (uni_args) walk(Defer{}, UniArgs{}); else walk(Defer{}, UniRuntime{});
+                if (__builtin_expect(list_degenerate(list), 0)) {
+                    list.init(dii, agent);
+                    in_range = ((dii <= delta_i) ? 1 : 0) - 1;
+                    s_all = 0.f; s_msk = 0.f; ncoll = 0;
+                    walk(NoDefer{}, UniRuntime{});
+                }
+            } else {
+                walk(NoDefer{}, UniRuntime{});
             }
         }
         // @phase filter_scan
