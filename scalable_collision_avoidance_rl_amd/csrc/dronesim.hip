@@ -1039,10 +1039,14 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             // offset (the compiler otherwise builds 64-bit per-lane addresses: three v_lshl_add_u64 and two v_mad_i64_i32)
             typedef __attribute__((address_space(1))) u32x4 gu32x4;   // (the asm would otherwise leave generic pointers)
             gu32x4 *gz4 = (gu32x4 *)gz, *gn4 = (gu32x4 *)gn;
+            // fixed-shape copy: a full wave of agents whose rows start 16-byte aligned -- always for kSym64 (checked on
+            // the host), every full wave of the workgroup-per-env geometries otherwise (wave-uniform test)
+            const bool fixed = SYM || (BLOCKGEO && nval == kWave &&
+                                       ((reinterpret_cast<uintptr_t>(gz) | reinterpret_cast<uintptr_t>(gn)) & 15u) == 0);
 #if !defined(DRONESIM_TRACE)                                   // (the trace build's stamps make hipcc lose the uniformity)
-            if (SYM) asm volatile("" : "+s"(gz4), "+s"(gn4));
+            if (SYM || BLOCKGEO) asm volatile("" : "+s"(gz4), "+s"(gn4));
 #endif
-            if (SYM) {
+            if (fixed) {
                 // full wave of one env, 16-byte aligned rows (checked on the host): fixed-shape copy, no loops
                 // (a branch-free variant -- surplus lanes of a ragged last round repeating a live lane's 16 bytes, so
                 // that the kernel's tail is one basic block -- was 0.14 us slower per launch: the stores got wider)
