@@ -1140,8 +1140,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 rs = any_rs;
             } else {
                 group_sync<WL>();
-                rs = valid && sred[2 * slot + 1] != 0;
-                any_rs = WL ? (__builtin_amdgcn_ballot_w64(rs) != 0ull) : (__syncthreads_or(rs ? 1 : 0) != 0);
+                const bool flag = sred[2 * slot + 1] != 0;
+                rs = valid && flag;
+                // one env per workgroup: every thread has just read the same word -- no second barrier to agree on it
+                any_rs = WL ? (__builtin_amdgcn_ballot_w64(rs) != 0ull) : (__builtin_amdgcn_readfirstlane((int)flag) != 0);
             }
             if (__builtin_expect(any_rs, 0)) {                // once per episode and env: out of line
                 if (!rand_act && rs)                          // the episode counter is only needed here: read it now (past
