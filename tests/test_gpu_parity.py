@@ -1047,8 +1047,10 @@ def test_workgroup_to_env_mapping_is_transparent(torch, N, epb):
     act = torch.tensor(rng.uniform(-1, 1, (Emax, N, 2)).astype(np.float32), device="cuda:0")
     full = make_env(N, G, 2, 2, np.ones(N), Emax, track_episodes=True)
     full.set_state(pos); full.step(act); full.step(act)
-    for blocks in (255, 256, 257, 513):
-        E = blocks * epb - (1 if blocks == 257 else 0)                    # one ragged last workgroup as well
+    for blocks in (255, 256, 257, 512, 513):
+        # ragged last workgroups as well: outside the permuted range (257) and inside it (512: the virtual workgroup
+        # that is short of envs is stepped by a different physical one)
+        E = blocks * epb - (1 if blocks in (257, 512) else 0)
         part = make_env(N, G, 2, 2, np.ones(N), E, track_episodes=True)
         part.set_state(pos[:E]); part.step(act[:E]); part.step(act[:E])
         for name in ("reward", "true_reward", "z", "nbr_idx", "n_coll", "done", "pos", "vel", "t"):
