@@ -62,6 +62,9 @@ constexpr int kPad = kChunk + 4;   // LDS slack so the last chunk may over-read 
 constexpr int kCells = 64;          // cells per axis of the bucket filter (coordinates are hashed: cell & 63)
 constexpr int kBucketRows = 66;     // cells 0..63 plus one empty guard row at either end
 constexpr int kBucketMinN = 40;     // packed envs smaller than this scan all partners (the tables would cost more)
+#if !defined(DRONESIM_SKIN)
+#define DRONESIM_SKIN 0.4f          // fused rollout: slack of the register-resident candidate list, in units of the reach
+#endif
 constexpr int kBucketMax = 10;      // candidates per agent beyond which the all-pairs scan is cheaper
 constexpr float kLn2 = 0.693147180559945309f;
 
@@ -2052,7 +2055,7 @@ int dronesim_rollout_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, float 
     KArgs a{};
     a.pos = pos; a.vel = vel; a.t = t; a.act = act; a.reward = reward; a.true_reward = true_reward;
     a.z = z; a.nbr_idx = nbr_idx; a.n_coll = n_coll; a.done = done; a.T = T;
-    a.skin = 0.4f * (p->d_hat_max + 2.0f * p->radius_max);
+    a.skin = DRONESIM_SKIN * (p->d_hat_max + 2.0f * p->radius_max);
     if ((rc = apply_ctl(p, ctl, false, a)) != 0) return rc;
     return launch(kRollout, p, a, E, stream);
 }
@@ -2078,7 +2081,7 @@ int dronesim_rollout_random(const DroneParams *p, const DroneEpisodeCtl *ctl, fl
     KArgs a{};
     a.pos = pos; a.vel = vel; a.t = t; a.act = nullptr; a.reward = reward; a.true_reward = true_reward;
     a.z = z; a.nbr_idx = nbr_idx; a.n_coll = n_coll; a.done = done; a.T = T;
-    a.skin = 0.4f * (p->d_hat_max + 2.0f * p->radius_max);
+    a.skin = DRONESIM_SKIN * (p->d_hat_max + 2.0f * p->radius_max);
     a.act_out = act_out;
     if ((rc = apply_ctl(p, ctl, true, a)) != 0) return rc;
     return launch(kRollout, p, a, E, stream);
