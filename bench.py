@@ -13,13 +13,20 @@ Timing: the K requested steps are captured as ONE hipGraph (whatever K is; a sho
 over, ~4000 launches per graph, because a replay costs 0.1-0.3 ms of GPU idle time whatever it holds) and the
 timed region replays that graph `repeats` times -- enough for >= 0.5 s -- between the two barriers, so a
 short `--steps 20` run measures the same thing as a long one: value = N * E * timed_steps / elapsed and
-ms_per_step = elapsed / timed_steps, timed_steps = K * graph_copies * repeats.  After every replay (every ~200
-steps when a replay is shorter than an episode) the path's only exchange runs inside the timed region: one fixed-order reduction of the per-env episode records + one all-gather (RCCL).
+ms_per_step = elapsed / timed_steps, timed_steps = K * graph_copies * repeats.
+
+The path's only exchange (train_problem.py:118-121: the per-episode log) runs inside the timed region at the
+reference's cadence: every 200 steps (one episode, drone_env.py:30) the capture holds one fixed-order reduction of
+the per-env episode records into the next slot of a small device ring, and after every replay ONE all-gather (RCCL
+over xGMI when world_size > 1) ships the ring's slots.  The line's `exchange` block says how many reductions and
+collectives the timed region held and whether a real collective ran.
 
 Default workload = BASELINE.json configs[2] (N=64 x E=4096 per GPU, Delta=1.0, G=28): the
-configuration the headline target (>= 1e7 agent-steps/s on 1 GPU) is quoted on; weak scaling:
-every extra GPU adds another 4096 envs (configs[3] at 8 GPUs).  --workload c2|c5 select the
-other single-GPU-sized configs.
+configuration the headline target (>= 1e7 agent-steps/s on 1 GPU) is quoted on.  --scaling weak (default):
+every extra GPU adds another 4096 envs (configs[3] at 8 GPUs); --scaling strong: configs[3]'s 32768 envs are ONE
+job split over the ranks.  --workload c2|c5 select the other single-GPU-sized configs; the default run also times
+them (c2, the c5 shard, the c5 shard with the float32 Gaussian policy in the loop) after the graded region and
+appends them as `other_workloads`.
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -107,12 +114,141 @@ def cpu_baseline(N, G, delta, budget_s=12.0):
                       f"{cores} OpenMP threads, {el:.1f} s"}
 
 
+def make_policy(torch, kind, precision, N, dev):
+    """Random-init per-agent networks of the reference's shapes (utils.py:255-302 / 55-108)."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    gp = torch.Generator().manual_seed(4321)
+    rw = lambda *sh: (torch.rand(*sh, generator=gp) * 2 - 1) * 0.2
+    h, nout, ok, sk = (300, 16, 1, 1) if kind == "softmax16" else (400, 4, 2, 2)
+    return BatchedMLP(rw(N, 6, h), rw(N, h), rw(N, h, h), rw(N, h), rw(N, h, nout), rw(N, nout), ok, sk,
+                      device=dev, seed=1234, precision=precision)
+
+
+def algorithmic_bytes(N, E, layer):
+    return BYTES_PER_AGENT_STEP * N * E + (BYTES_PER_ENV_STEP + (BYTES_PER_ENV_STEP_RECORD if layer else 0)) * E
+
+
+def step_kernel_ms(torch, env, pool, n_samp, reps=10):
+    """Duration of the step kernel per launch by HIP events on the launch stream (torch's current stream = the stream
+    handed to dronesim_step): events bracket a hipGraph holding ONLY `n_samp` back-to-back step launches."""
+    T_ep = pool.shape[0]
+    kgraph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(kgraph):
+        for s in range(n_samp):
+            env.step(pool[s % T_ep])
+    kgraph.replay(); torch.cuda.synchronize()
+    samples = []
+    for _ in range(reps):
+        env.reset(renew_obstacles=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); kgraph.replay(); e1.record(); torch.cuda.synchronize()
+        samples.append(e0.elapsed_time(e1) / n_samp)
+    return float(np.median(samples))
+
+
+def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25):
+    """One of the other BASELINE configs, timed in this process after the graded region: the same step path
+    (episode layer, hipGraph replay), single GPU.  Returns the block appended under `other_workloads`."""
+    from scalable_collision_avoidance_rl_amd import drones, max_time_steps
+    N, E, G, delta, label = WORKLOADS[name]
+    env = drones(N, 0, [G, G], "O", k_closest=2, deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, device=dev,
+                 seed=1234, batched=True, auto_reset=True, track_episodes=True)
+    T_ep = max_time_steps
+    g = torch.Generator(device=dev).manual_seed(99)
+    pool = torch.rand(T_ep, E, N, 2, device=dev, generator=g) * 2 - 1
+    policy = make_policy(torch, policy_kind, "f32", N, dev) if policy_kind else None
+
+    def one_step(s):
+        if policy is None:
+            env.step(pool[s % T_ep])
+        else:
+            act, _ = policy.sample_action(env.z, env=env)
+            env.step(act)
+
+    for s in range(10):
+        one_step(s)
+    torch.cuda.synchronize()
+    L = 2000 if policy is None else 100                # launches per graph (a policy step is ~100x an env step)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for s in range(L):
+            one_step(s)
+    graph.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); graph.replay(); torch.cuda.synchronize()
+    one = max(time.perf_counter() - t0, 1e-6)
+    repeats = max(1, int(np.ceil(min_seconds / one)))
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(repeats):
+        graph.replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    steps = L * repeats
+    kern_ms = step_kernel_ms(torch, env, pool, 5 * T_ep, reps=5)
+    byt = algorithmic_bytes(N, E, True)
+    out = {"workload": label + (f" + float32 {policy_kind} policy in the loop (BASELINE configs[4], one shard)" if policy else ""),
+           "value": N * E * steps / el, "unit": "agent-steps/s", "ms_per_step": el / steps * 1e3, "timed_steps": steps,
+           "timed_seconds": el, "step_kernel_ms": kern_ms,
+           "roofline": {"bound": "hbm", "achieved": byt / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": byt / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byt,
+                        "kernel": "drone_kernel<K=2,FAR=0,step,episode layer>"}}
+    if policy is not None:                             # the policy kernel alone (exact-f32 MFMA), same events-around-a-graph method
+        pg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(pg):
+            for _ in range(20):
+                policy.sample_action(env.z, env=env)
+        pg.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); pg.replay(); e1.record(); torch.cuda.synchronize()
+        pol_ms = e0.elapsed_time(e1) / 20
+        flops = 2.0 * E * N * (policy.d_in * policy.h1 + policy.h1 * policy.h2 + policy.h2 * policy.nout)
+        out["policy_kernel_ms"] = pol_ms
+        out["policy_roofline"] = {"bound": "mfma", "achieved": flops / (pol_ms * 1e-3) / 1e12, "peak": 157.3,
+                                  "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / 157.3,
+                                  "kernel": "mlp3_kernel (v_mfma_f32_32x32x2_f32, exact float32)"}
+    del graph, env, pool
+    torch.cuda.empty_cache()
+    return out
+
+
+RCCL_PROBE = r"""
+import os, time, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29653")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+src = torch.arange(8, dtype=torch.float64, device="cuda").view(1, 8); out = torch.empty(1, 8, dtype=torch.float64, device="cuda")
+for _ in range(20): dist.all_gather_into_tensor(out, src)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200): dist.all_gather_into_tensor(out, src)
+torch.cuda.synchronize(); print("RCCL_US", (time.perf_counter() - t0) / 200 * 1e6, bool(torch.equal(out, src)))
+dist.destroy_process_group()
+"""
+
+
+def rccl_probe():
+    """Latency of the exchange's collective through RCCL in a world of ONE (a separate process with its own 60 s
+    limit, so that a stuck rendezvous cannot take the benchmark with it).  None when it did not run."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", RCCL_PROBE], capture_output=True, text=True, timeout=90)
+        for line in r.stdout.splitlines():
+            if line.startswith("RCCL_US"):
+                _, us, ok = line.split()
+                return {"world_size": 1, "all_gather_into_tensor_8_doubles_us": float(us), "result_correct": ok == "True",
+                        "note": "RCCL collective of the exchange, timed back to back in a world of one (separate process)"}
+    except (subprocess.SubprocessError, OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: envs-per-gpu fixed (4096 at c3: configs[3] at 8 GPUs); strong: the c3 shape's 8-GPU job "
+                         "(32768 envs = BASELINE configs[3]) is ONE job split over however many ranks run")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of hipGraph replay")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="minimum length of the timed region (graph replays)")
@@ -126,12 +262,15 @@ def main():
                          "two-part float16 split, float32-accurate; bf16 = opt-in fast path, ~1e-2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the c2 / c5 side measurements appended to the default single-GPU run")
+    ap.add_argument("--no-rccl-probe", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from scalable_collision_avoidance_rl_amd import drones, max_time_steps
-    from scalable_collision_avoidance_rl_amd.sharding import reduce_episode_records, summarize_episodes, all_gather_stats
+    from scalable_collision_avoidance_rl_amd.sharding import summarize_episodes, all_gather_stats
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -149,11 +288,16 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    cdev = dev if backend == "nccl" else "cpu"           # where small control tensors of the collectives live
 
     N, e_gpu, G, delta, label = WORKLOADS[args.workload]
     if args.envs_per_gpu:
         e_gpu = args.envs_per_gpu
-    E_global = e_gpu * world
+    if args.scaling == "strong":
+        E_global = e_gpu * 8                             # the 8-GPU job of the workload (c3: configs[3], 32768 envs)
+        label += f" -- strong scaling: {E_global} envs in all (BASELINE configs[3] when c3), split over {world} rank(s)"
+    else:
+        E_global = e_gpu * world
     layer = not args.no_episode_layer
     env = drones(N, 0, [G, G], "O", k_closest=2, deltas=np.ones(N) * delta, simplify_zstate=True,
                  n_envs=E_global, device=dev, seed=1234, rank=rank, world_size=world, batched=True,
@@ -165,31 +309,19 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     pool = torch.rand(T_ep, E, N, 2, device=dev, generator=g) * 2 - 1
 
-    policy = None
-    if args.policy != "random":                     # random-init per-agent networks of the reference's shapes
-        from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
-        gp = torch.Generator().manual_seed(4321)
-        rw = lambda *sh: (torch.rand(*sh, generator=gp) * 2 - 1) * 0.2
-        h, nout, ok, sk = (300, 16, 1, 1) if args.policy == "softmax16" else (400, 4, 2, 2)   # utils.py:255-302 / 55-108
-        policy = BatchedMLP(rw(N, 6, h), rw(N, h), rw(N, h, h), rw(N, h), rw(N, h, nout), rw(N, nout), ok, sk,
-                            device=dev, seed=1234, precision=args.policy_precision)
+    policy = make_policy(torch, args.policy, args.policy_precision, N, dev) if args.policy != "random" else None
+    launches = 0                                         # step launches issued on this rank (checked against the device records)
 
     def one_step(s):
+        nonlocal launches
         if policy is None:
             env.step(pool[s % T_ep])
         else:                                       # obs -> sample_action -> step (SAC_agents.py:170-180, train_problem.py:91-94)
             act, _ = policy.sample_action(env.z, env=env)
             env.step(act)
+        launches += 1
         if not layer and (s + 1) % T_ep == 0:       # plain path: explicit reset kernel + observe (train_problem.py:132)
             env.reset(renew_obstacles=False)
-
-    # the path's only exchange (train_problem.py:118-121: what is logged per episode), off the per-step path:
-    # local fixed-order reduction of the episode records on the step stream, then ONE all-gather of 8 doubles
-    exchanges = []
-
-    def exchange():
-        tot = env.episode_totals()                  # one launch on the current stream; device tensor [8]
-        exchanges.append(all_gather_stats(tot, async_op=True))   # RCCL on its own stream; the rollout is not held up
 
     def barrier():
         torch.cuda.synchronize()
@@ -214,6 +346,7 @@ def main():
     # the device, so every replay continues the rollout: episodes end, are logged and restart inside the replays.
     graph = None
     K = args.steps
+    ring = None                                          # [slots, 8] float64: one in-graph reduction per episode length
     if not args.no_graph:
         if not layer:
             while step_no % T_ep:                   # plain path resets by step index: align the capture to an episode
@@ -224,68 +357,93 @@ def main():
         # ONE graph of ~4000 launches (the episode layer keeps every counter on the device, so the copies simply
         # continue the rollout), and the per-step figure of `--steps 20` is that of `--steps 2000`
         copies = max(1, -(-4000 // K)) if layer else 1
+        L = K * copies
+        # the exchange's local half at the reference's cadence, INSIDE the capture: after every T_ep-th launch one
+        # fixed-order reduction of the episode records (train_problem.py:118-121 logs once per episode) into its own
+        # ring slot; a capture shorter than an episode gets one at its end
+        slots = max(1, L // T_ep)
+        ring = torch.zeros(slots, 8, dtype=torch.float64, device=dev)
+        launches_before = launches
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for s in range(K * copies):
+            for s in range(L):
                 one_step(s)
+                if (s + 1) % T_ep == 0 and (s + 1) // T_ep <= slots and L >= T_ep:
+                    env.episode_totals(out=ring[(s + 1) // T_ep - 1])
+            if L < T_ep:
+                env.episode_totals(out=ring[0])
+        launches = launches_before                       # capturing enqueues nothing
         for _ in range(2):                          # untimed replays: instantiate + clocks
-            graph.replay()
+            graph.replay(); launches += L
         torch.cuda.synchronize()
-        t0 = time.perf_counter(); graph.replay(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); graph.replay(); torch.cuda.synchronize(); launches += L
         one = max(time.perf_counter() - t0, 1e-6)
         if world > 1:                               # every rank must replay (and exchange) the same number of times
-            o = torch.tensor([one], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            o = torch.tensor([one], dtype=torch.float64, device=cdev)
             dist.all_reduce(o, op=dist.ReduceOp.MIN)
             one = float(o.item())
         repeats = max(1, int(np.ceil(1.2 * args.min_seconds / one)))
     else:
-        repeats, copies = 1, 1
-    L = K * copies                                       # launches per replay
-    log_every = max(1, T_ep // L) if L < T_ep else 1     # replays between two exchanges (~ once per episode)
+        repeats, copies, L, slots = 1, 1, K, 1
+        ring = torch.zeros(1, 8, dtype=torch.float64, device=dev)
+
+    # the exchange's collective half: ONE all-gather per replay of the ring's slots (64 B per slot and rank), issued
+    # async on RCCL's own stream behind the replay that filled them; the rollout's next replay is not held up
+    exchanges = []
+
+    def exchange():
+        exchanges.append(all_gather_stats(ring.view(-1), async_op=True))
 
     barrier()
     t0 = time.perf_counter()
     if graph is not None:
         for r in range(repeats):
-            graph.replay()
-            if (r + 1) % log_every == 0:
-                exchange()
+            graph.replay(); launches += L
+            exchange()
     else:
         for s in range(K):
             one_step(step_no); step_no += 1
-        exchange()
+            if (s + 1) % T_ep == 0 or s == K - 1:
+                env.episode_totals(out=ring[0]); exchange()
     for _, work in exchanges:                       # every exchange of the timed region has completed
         if work is not None:
             work.wait()
     barrier()
     elapsed = time.perf_counter() - t0
     total_steps = L * repeats
-    # final exchange: global per-episode figures (the same reduction + all-gather as inside the timed region)
-    summary = reduce_episode_records(env)
-    summary["exchanges_in_timed_region"] = len(exchanges)
-    last = exchanges[-1][0].to(dev) if exchanges else None
-    summary["last_timed_exchange_episodes"] = None if last is None else float(last.double().sum(0)[4])
+    reductions = (slots * repeats) if graph is not None else len(exchanges)
+    # final exchange: global per-episode figures from one more reduction + all-gather of the same kind
+    final = all_gather_stats(env.episode_totals())
+    summary = summarize_episodes(final, N)
+    last = exchanges[-1][0].to(dev).view(-1, slots, 8) if exchanges else None      # [world, slots, 8]
+    summary["last_timed_exchange_episodes"] = None if last is None else float(last[:, -1, 4].double().sum())
+    # the device-side records must account for every launch this process issued: env_steps = launches x envs
+    if layer:
+        own = env.episode_totals().cpu()
+        recorded = float(own[3] + own[7])
+        assert recorded == float(launches) * E, f"episode records hold {recorded} env-steps, {launches} launches x {E} envs issued"
+    launch_check = {"launches_issued_per_rank": launches, "envs_per_rank": E,
+                    "env_steps_recorded_all_ranks": summary["env_steps"],
+                    "ok": (not layer) or summary["env_steps"] == float(launches) * E_global}
 
-    # Duration of the dominant kernel (drone_kernel<step>) per launch, by HIP events on the launch stream
-    # (torch's current stream = the stream handed to dronesim_step): events bracket a hipGraph holding
-    # ONLY `n_samp` back-to-back step launches, so (t1 - t0) / n_samp is the kernel's duration including the
-    # ~0.2 us dependent-launch boundary and excluding host launch latency.  rocprofv3 --kernel-trace --stats
-    # of this command reports the same kernel's average duration (profiles/).
-    # With the episode layer the graph holds twenty episodes (the in-kernel resets fire inside it, as in the timed
-    # region); the ~0.1 ms a graph replay costs is then < 0.5 % of the bracketed time.
-    n_samp = 20 * T_ep if layer else T_ep
-    kgraph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(kgraph):
-        for s in range(n_samp):
-            env.step(pool[s % T_ep])
-    kgraph.replay(); torch.cuda.synchronize()
-    samples = []
-    for _ in range(10):
-        env.reset(renew_obstacles=False)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); kgraph.replay(); e1.record(); torch.cuda.synchronize()
-        samples.append(e0.elapsed_time(e1) / n_samp)
-    kern_ms = float(np.median(samples))
+    # measured latency of the exchange's collective on this job's process group (world > 1), outside the timed region
+    allgather_us = None
+    if world > 1:
+        src = ring.view(-1)
+        for _ in range(5):
+            all_gather_stats(src)
+        barrier(); t1 = time.perf_counter()
+        for _ in range(50):
+            all_gather_stats(src)
+        torch.cuda.synchronize()
+        allgather_us = (time.perf_counter() - t1) / 50 * 1e6
+
+    # Duration of the dominant kernel (drone_kernel<step>) per launch, by HIP events on the launch stream: events
+    # bracket a hipGraph holding ONLY `n_samp` back-to-back step launches, so (t1 - t0) / n_samp is the kernel's
+    # duration including the dependent-launch boundary and excluding host launch latency.  rocprofv3 --kernel-trace
+    # --stats of this command reports the same kernel's average duration (profiles/).  With the episode layer the graph
+    # holds twenty episodes (the in-kernel resets fire inside it, as in the timed region).
+    kern_ms = step_kernel_ms(torch, env, pool, 20 * T_ep if layer else T_ep)
 
     # secondary figure: the same workload through dronesim_rollout (200 steps fused in ONE launch, actions
     # known up front -- RandomAgent rollouts); every per-step output except the per-step state is written
@@ -317,24 +475,30 @@ def main():
     except RuntimeError:
         rr_us = None
 
-    el = torch.tensor([elapsed, eager_elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    el = torch.tensor([elapsed, eager_elapsed], dtype=torch.float64, device=cdev)
+    per_rank = None
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        mine = torch.tensor([kern_ms, elapsed, float(E)], dtype=torch.float64, device=cdev)
+        allr = torch.empty(world, 3, dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr, mine.view(1, 3))
+        per_rank = [{"rank": r, "step_kernel_ms": float(allr[r, 0]), "timed_seconds": float(allr[r, 1]), "envs": int(allr[r, 2])}
+                    for r in range(world)]
     elapsed, eager_elapsed = float(el[0].item()), float(el[1].item())
 
     if rank == 0:
         agent_steps = N * E_global * total_steps
         value = agent_steps / elapsed
-        bytes_launch = BYTES_PER_AGENT_STEP * N * E + (BYTES_PER_ENV_STEP + (BYTES_PER_ENV_STEP_RECORD if layer else 0)) * E
+        bytes_launch = algorithmic_bytes(N, E, layer)
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(args.workload) if e_gpu == WORKLOADS[args.workload][1] else (None, None)
+        traffic, traffic_src = pmc_traffic(args.workload) if (e_gpu == WORKLOADS[args.workload][1] and E == e_gpu) else (None, None)
         out = {
             "metric": "env agent-steps/sec (n_agents x n_envs x steps)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "repeats": repeats, "graph_copies": copies, "timed_steps": total_steps, "timed_seconds": elapsed,
-            "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / total_steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": label, "n_agents": N, "envs_per_gpu": e_gpu, "n_envs_total": E_global,
+            "config": {"workload": label, "n_agents": N, "envs_per_gpu": E, "n_envs_total": E_global,
                        "grid": G, "delta": delta, "k_closest": 2, "simplify_zstate": True,
                        "launch": ((f"hipGraph of the {K} requested steps" + (f", captured {copies}x over ({L} launches)" if copies > 1 else "") +
                                    f", replayed {repeats}x in the timed region") if graph is not None else "eager"),
@@ -347,22 +511,51 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "drone_kernel<K=2,FAR=0,step,%s>" % ("episode layer" if layer else "plain"), "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
+            "exchange": {"what": "per-episode log of train_problem.py:118-121: fixed-order reduction of the per-env episode "
+                                 "records (dronesim_episode_reduce, in the capture) + all-gather of the reduced 8-double vectors",
+                         "reduce_every_steps": T_ep if L >= T_ep else L,
+                         "reductions_in_timed_region": reductions,
+                         "collectives_in_timed_region": len(exchanges),
+                         "doubles_per_collective_and_rank": int(ring.numel()),
+                         "collective": ("all_gather_into_tensor over %s, world_size %d, async on the collective's stream"
+                                        % ("RCCL (backend nccl)" if backend == "nccl" else backend, world)) if world > 1 else
+                                       "none: world_size 1, the reduced vectors are already everywhere (see rccl_probe)",
+                         "real_collective_ran": bool(world > 1),
+                         "collective_latency_us": allgather_us},
+            "launch_check": launch_check,
             "episode_end_stats": summary,
             "eager": {"value": N * E_global * args.steps / eager_elapsed, "ms_per_step": eager_elapsed / args.steps * 1e3,
                       "note": "the same K steps launched one by one from Python (host launch latency included)"},
             "fused_rollout": None if ro_us is None else {
                 "us_per_step_per_gpu": ro_us, "agent_steps_per_s_per_gpu": N * E / ro_us * 1e6,
+                "roofline_frac_52B": 52.0 * N * E / (ro_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "note": "dronesim_rollout: 200 steps per launch, 52 B/agent-step (no per-step state write-back)",
                 "random_actions_in_kernel": None if rr_us is None else {
                     "us_per_step_per_gpu": rr_us, "agent_steps_per_s_per_gpu": N * E / rr_us * 1e6,
                     "note": "dronesim_rollout_random: actions drawn in the kernel (no action pool, 44 B/agent-step), "
                             "episode records + in-kernel reset on"}},
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(N, G, delta, args.cpu_budget)
             out["cpu_baseline"]["reference"] = reference_record(args.workload)
         else:
             out["cpu_baseline"] = None
+        # the other BASELINE configs, timed by THIS process after the graded region (single-GPU default run only)
+        if (world == 1 and not args.no_other_workloads and args.workload == "c3" and policy is None and layer
+                and args.scaling == "weak" and not args.envs_per_gpu):
+            del pool
+            torch.cuda.empty_cache()
+            other = {}
+            for key, wl, pk in (("c2", "c2", None), ("c5_env", "c5", None), ("c5_gaussian_f32", "c5", "gaussian")):
+                try:
+                    other[key] = side_workload(torch, dev, wl, pk)
+                except Exception as ex:                 # a side measurement must never cost the headline line
+                    other[key] = {"error": f"{type(ex).__name__}: {ex}"}
+            out["other_workloads"] = other
+        if world == 1 and not args.no_rccl_probe:
+            out["exchange"]["rccl_probe"] = rccl_probe()
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

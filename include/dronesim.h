@@ -27,7 +27,7 @@
  *    is thrown across the ABI.  dronesim_last_error() gives a thread-local
  *    description of the last failure.
  *  - Re-entrant; the only mutable state is that thread-local string and a per-device record of which kernels
- *    have been opted into > 64 KiB of dynamic LDS (hipFuncSetAttribute; guarded by a mutex).
+ *    have been opted into > 48 KiB of dynamic LDS (hipFuncSetAttribute; guarded by a mutex).
  *  - One process drives one GPU; multi-GPU runs shard the E axis across
  *    processes (env_base keeps random streams independent of the sharding).
  */
@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DRONESIM_VERSION 201           /* 0.2.1 */
+#define DRONESIM_VERSION 300           /* 0.3.0: DroneEpisodeCtl grew z_final / nbr_final / pos_final */
 #define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
 #define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
 
@@ -169,6 +169,16 @@ typedef struct DroneEpisodeCtl {
     uint64_t seed;
     int64_t env_base;
     int32_t *episode;           /* [E] device, resets seen per env (in/out)                          */
+    /* Terminal observation under auto_reset (all three optional, NULL = not wanted).  The reference's step() returns
+     * the z-states and state of the FINAL state of an episode (drone_env.py:258) and its loop stores them as `new_z` of
+     * the last transition (utils.py:244-249) before it resets (train_problem.py:132).  With auto_reset the launch that
+     * ends an episode overwrites z / nbr_idx / pos with the NEW episode's first observation; when these pointers are
+     * given, the finished env's terminal rows are kept here instead of being lost: written ONLY for envs whose `done`
+     * fired in this launch (rows of other envs are left untouched), same layouts as z / nbr_idx / pos
+     * ([T][...] like z in the fused rollouts).                                                                  */
+    float *z_final;             /* [E][N][k+1][c]                                                    */
+    int32_t *nbr_final;         /* [E][N][k+1]                                                       */
+    float *pos_final;           /* [E][N][2]                                                         */
 } DroneEpisodeCtl;
 
 /* dronesim_step / dronesim_rollout with episode bookkeeping and optional in-kernel auto-reset.  ctl == NULL

@@ -51,7 +51,8 @@ class DroneEpisodeAcc(C.Structure):
 class DroneEpisodeCtl(C.Structure):
     """Mirror of `struct DroneEpisodeCtl` (include/dronesim.h)."""
     _fields_ = [("acc", C.c_void_p), ("auto_reset", C.c_int32), ("div_x", C.c_int32), ("div_y", C.c_int32),
-                ("pitch", C.c_float), ("seed", C.c_uint64), ("env_base", C.c_int64), ("episode", C.c_void_p)]
+                ("pitch", C.c_float), ("seed", C.c_uint64), ("env_base", C.c_int64), ("episode", C.c_void_p),
+                ("z_final", C.c_void_p), ("nbr_final", C.c_void_p), ("pos_final", C.c_void_p)]
 
 
 class DroneParamsF64(C.Structure):

@@ -36,18 +36,35 @@ class _ReferencePickle:
     __name__ = "reference_pickle"
 
     class Unpickler(pickle.Unpickler):
-        """Resolves ONLY what such a file legitimately names: torch's tensor / storage rebuild helpers and
-        `torch.nn` modules, `collections.OrderedDict`, NumPy's array reconstruction, builtins' plain containers, and
-        the reference's own classes (as stand-ins).  Anything else raises instead of being imported -- a pickle is
-        code, and a file from an untrusted source must still not be opened with this loader."""
-        _ALLOWED_PREFIXES = ("torch._utils", "torch.nn.", "torch.storage", "torch._tensor", "torch.serialization",
-                             "numpy.core.multiarray", "numpy._core.multiarray", "numpy.core.numeric", "numpy._core.numeric")
-        _ALLOWED = {("collections", "OrderedDict"), ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "list"),
+        """Resolves ONLY what such a file legitimately names, as EXACT (module, name) pairs: torch's tensor /
+        parameter rebuild helpers, its storage classes, the `torch.nn` layer classes the reference's networks are made
+        of (utils.py:22-117, 271-302), `collections` containers, NumPy's array reconstruction, builtins' plain
+        containers, and the reference's own classes (as stand-ins).  No module prefix is trusted: `torch.storage`,
+        `torch.serialization`, `torch._utils` and `torch.nn` all hold callables that run arbitrary code when a pickle
+        names them (`torch.storage._load_from_bytes` -> `torch.load(..., weights_only=False)`, `torch.serialization.load`,
+        `torch.nn.utils...`).  Anything else raises instead of being imported -- a pickle is code, and a file from an
+        untrusted source must still not be opened with this loader."""
+        _STORAGES = tuple(f"{t}Storage" for t in ("Float", "Double", "Half", "BFloat16", "Long", "Int", "Short", "Char",
+                                                  "Byte", "Bool", "ComplexFloat", "ComplexDouble", "Untyped", "Typed"))
+        _ALLOWED = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("collections", "deque"),
+                    ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "list"),
                     ("builtins", "dict"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"),
                     ("builtins", "complex"), ("builtins", "bool"), ("builtins", "slice"), ("builtins", "range"),
-                    ("numpy", "ndarray"), ("numpy", "dtype"), ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
-                    ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"), ("torch.optim.adam", "Adam"),
-                    ("collections", "defaultdict"), ("collections", "deque"), ("_codecs", "encode")}
+                    ("_codecs", "encode"),
+                    ("numpy", "ndarray"), ("numpy", "dtype"),
+                    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"), ("torch", "Tensor"),
+                    ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"),
+                    ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+                    ("torch._tensor", "_rebuild_from_type_v2"),
+                    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+                    ("torch.nn.parameter", "Parameter"),
+                    ("torch.nn.modules.linear", "Linear"), ("torch.nn.modules.linear", "Identity"),
+                    ("torch.nn.modules.activation", "ReLU"), ("torch.nn.modules.activation", "Softmax"),
+                    ("torch.nn.modules.activation", "Tanh"), ("torch.nn.modules.activation", "Sigmoid"),
+                    ("torch.nn.modules.container", "Sequential"), ("torch.nn.modules.container", "ModuleList"),
+                    ("torch.optim.adam", "Adam")} | {("torch", s) for s in _STORAGES}
 
         def find_class(self, module, name):
             if module in _REFERENCE_MODULES:
@@ -57,8 +74,7 @@ class _ReferencePickle:
                     return _standin(module, name)
             if module == "__builtin__":                              # protocol-2 spelling of builtins
                 module = "builtins"
-            if (module, name) in self._ALLOWED or module.startswith(self._ALLOWED_PREFIXES) or \
-                    (module == "torch" and name.endswith(("Storage", "Tensor"))):
+            if (module, name) in self._ALLOWED:
                 return super().find_class(module, name)
             raise pickle.UnpicklingError(f"{module}.{name} is not something a saved list of the reference's networks "
                                          "contains; refusing to import it")

@@ -102,6 +102,8 @@ struct KArgs {
     float pitch;
     int *episode;
     float *act_out;                 // rand_act: optional record of the actions drawn, [T][E][N][2]
+    float *z_final, *pos_final;     // auto_reset: terminal observation / state of the envs that finish (or nullptr)
+    int *nbr_final;
     int lds_tail;                   // byte offset of the bookkeeping regions behind the bucket tables
     int samp_tbl, samp_shift;       // in-kernel reset: entries of the sampling table per env slot (2^k >= 2 N), 32 - k
 };
@@ -1151,10 +1153,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             if (__builtin_expect(any_rs, 0)) {                // once per episode and env: out of line
                 if (!rand_act && rs)                          // the episode counter is only needed here: read it now (past
                     epi = (uint32_t)__builtin_nontemporal_load(a.episode + env);   // L1: an earlier reset of this launch wrote it)
-                if (rs && agent == 0) {
-                    sred[2 * slot + 1] = 0;
-                    a.episode[env] = (int)(epi + 1u);
-                }
+                if (rs && agent == 0) a.episode[env] = (int)(epi + 1u);
+                // terminal state of the finished episode (drone_env.py:258 returns it; the reset below overwrites it)
+                if (rs && a.pos_final != nullptr) st_out2(a.pos_final + 2 * (so + wga0 + lane), xi, yi);
                 if (rs && has_acc && agent < 2) {                 // retire the finished episode (train_problem.py:118-121)
                     double *tot = a.acc + 8 * (size_t)env + 4 + 2 * agent;        // agent 0: done_return, done_true_return
                     if (agent == 0) {                                             // agent 1: done_collisions, done_len
@@ -1183,6 +1184,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     if (rs)
                         for (int o = agent; o < nt; o += N) tbl[o] = make_int2(-1, 0x7fffffff);
                     group_sync<WL>();
+                    // the "re-sample this env" word is cleared only now: every wave of the workgroup has read it (the
+                    // barrier above) -- clearing it right behind agent 0's own read let a late wave see 0, skip this
+                    // block and miss its barriers
+                    if (!SYM && round == 0 && rs && agent == 0) sred[2 * slot + 1] = 0;
                     int prop = node, h = 0;
                     if (rs) {
                         if (node < 0)
@@ -1203,8 +1208,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     ++round;
                 } while (more && round < (1u << 20));
                 if (rs) {
-                    const int idx = node / a.div_y, jdx = node - idx * a.div_y;
-                    xi = (float)idx * a.pitch; yi = (float)jdx * a.pitch;         // drone_env.py:196-205
+                    if (node >= 0) {                              // (an agent still unsettled after 2^20 rounds keeps its place)
+                        const int idx = node / a.div_y, jdx = node - idx * a.div_y;
+                        xi = (float)idx * a.pitch; yi = (float)jdx * a.pitch;     // drone_env.py:196-205
+                    }
                     vxi = 0.f; vyi = 0.f;                                         // :189
                     tcur = 0;                                                     // :100
                     epi += 1u;
@@ -1214,6 +1221,24 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
                 group_sync<WL>();
                 __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this wave's earlier z / Ni / state stores
+                if (rs && (a.z_final != nullptr || a.nbr_final != nullptr)) {
+                    // terminal observation (the `new_z` of the episode's last transition, utils.py:244-249): this lane's
+                    // rows of z / Ni as the hot path has just written them -- all of them by THIS wave, whose stores have
+                    // been acknowledged above -- are read back past L1 and kept before the re-observation replaces them
+                    const size_t row = so + wga0 + lane;
+                    if (a.z_final != nullptr) {
+                        const float *src = a.z + row * (size_t)((K + 1) * zc);
+                        float *dst = a.z_final + row * (size_t)((K + 1) * zc);
+                        for (int w = 0; w < (K + 1) * zc; ++w) st_out(dst + w, __builtin_nontemporal_load(src + w));
+                    }
+                    if (a.nbr_final != nullptr) {
+                        const int *src = a.nbr_idx + row * (size_t)(K + 1);
+                        int *dst = a.nbr_final + row * (size_t)(K + 1);
+#pragma unroll
+                        for (int w = 0; w <= K; ++w) st_out(dst + w, __builtin_nontemporal_load(src + w));
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0f70);           // the read-back has returned before the rows are rewritten
+                }
                 if (rs) {                                         //           have landed before they are overwritten
                     list.init(dii, agent);
                     in_range = ((dii <= delta_i) ? 1 : 0) - 1;
@@ -1810,7 +1835,7 @@ int check_params(const DroneParams *p, int E)
 #endif   // DRONESIM_PART <= 0
 
 #if DRONESIM_PART != 0
-// more than 64 KiB of dynamic LDS (envs of several hundred agents) has to be opted into once per kernel
+// more than 48 KiB of dynamic LDS (envs of several hundred agents) has to be opted into once per kernel
 template <int K, bool FAR, int MODE, int GEO, bool EPI>
 hipError_t launch_one(const KArgs &a, const Geometry &g, hipStream_t s)
 {
@@ -1924,6 +1949,7 @@ int apply_ctl(const DroneParams *p, const DroneEpisodeCtl *ctl, bool rand_act, K
         if (M < (uint64_t)p->N) return fail(DRONESIM_EINVAL, "lattice has fewer nodes than agents (random.sample would raise)");
         if (M > 0xFFFFFFFFull) return fail(DRONESIM_EUNSUPPORTED, "lattice larger than 2^32 nodes");
         a.lat_M = (uint32_t)M; a.div_y = ctl->div_y; a.pitch = ctl->pitch;
+        a.z_final = ctl->z_final; a.nbr_final = ctl->nbr_final; a.pos_final = ctl->pos_final;
     }
     return DRONESIM_OK;
 }

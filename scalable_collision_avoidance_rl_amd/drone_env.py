@@ -114,12 +114,15 @@ class drones:
     rollout loop logs, train_problem.py:98-100, in per-env device records updated by the step kernel
     itself), ``auto_reset`` (envs whose ``done`` fires are reset and re-observed inside the same step
     launch -- what train_problem.py:132 does after the ``while not finished`` loop; implies
-    ``track_episodes``)."""
+    ``track_episodes``), ``keep_final_obs`` (with ``auto_reset``: the finished episode's terminal observation and
+    state -- what the reference's ``step()`` returns on its last call, drone_env.py:258, and its loop stores as
+    ``new_z``, utils.py:244-249 -- are kept in ``z_final`` / ``nbr_final`` / ``pos_final`` instead of being lost to
+    the new episode's first observation; rows are valid for the envs whose ``finished`` flag the step raised)."""
 
     def __init__(self, n_agents: int, n_obstacles: int, grid: list, end_formation: str, k_closest=2,
                  deltas: np.ndarray = None, simplify_zstate=False, *, n_envs: int = 1, device=None,
                  seed: int = None, rank: int = 0, world_size: int = 1, batched: bool = None,
-                 track_episodes: bool = None, auto_reset: bool = False) -> None:
+                 track_episodes: bool = None, auto_reset: bool = False, keep_final_obs: bool = False) -> None:
         import torch
         from . import _native
 
@@ -140,9 +143,14 @@ class drones:
         self.simplify_zstate = bool(simplify_zstate)
         self.internal_t = 0
         self.collision_weight = 0.2                   # live attribute, read at every step (drone_env.py:72, 270)
-        self._drone_radius = np.ones(self.n_agents) * DRONE_RADIUS
         self._alloc_done = False
+        self._deltas = None
+        self._set_const("_drone_radius", np.ones(self.n_agents) * DRONE_RADIUS, "_radius")
         self.auto_reset = bool(auto_reset)
+        self.keep_final_obs = bool(keep_final_obs)
+        if self.keep_final_obs and not self.auto_reset:
+            raise ValueError("keep_final_obs only has a meaning with auto_reset (without it z_states IS the terminal "
+                             "observation until the caller resets)")
         self.track_episodes = self.auto_reset if track_episodes is None else bool(track_episodes) or self.auto_reset
         self.A = np.eye(dim)
         self.B = np.eye(dim) * dt
@@ -157,12 +165,13 @@ class drones:
             raise ValueError(str(end_formation) + " is Not a valid end formation identifier")
 
         self.obstacles = self.create_obstacles(n_obstacles)
-        self.end_points, self._d_safety = formation_O(N, grid, self.drone_radius)
+        self.end_points, d_safety = formation_O(N, grid, self.drone_radius)
+        self._set_const("_d_safety", d_safety, "_d_hat")
         if not np.all(self.d_safety > 0):
             raise ValueError(f"safety distance d_hat = {self.d_safety.min():.2f} <= 0: the goal ring does not fit "
                              f"{N} agents on grid {grid} (need 0.9*G*sin(pi/N) > 0.2); the reference's reward is "
                              "degenerate there")
-        self._deltas = clip_deltas(deltas, self.d_safety)
+        self._set_const("_deltas", self.d_safety if deltas is None else deltas, "_delta")   # clipped, with the reference's warning
 
         # sharding of the env axis
         self.n_envs_global = int(n_envs)
@@ -190,11 +199,19 @@ class drones:
     # The reference reads self.deltas / self.d_safety / self.drone_radius on every step (drone_env.py:242): assigning
     # them here re-uploads the device copies and takes effect at the next launch.
     def _set_const(self, name, value, tensor_name):
-        arr = np.array(value, np.float64).reshape(self.n_agents)
+        # a scalar broadcasts over the agents; `deltas` is clipped against d_safety exactly as the constructor does
+        # (drone_env.py:85-91); the stored array is READ-ONLY so that an in-place edit (`env.deltas[i] = x`), which the
+        # reference would pick up on its next step but which cannot reach the device copy, raises instead of being lost
+        arr = np.array(np.broadcast_to(np.asarray(value, np.float64), (self.n_agents,)))
+        if name == "_deltas":
+            arr = np.array(clip_deltas(arr, self.d_safety))
+        arr.setflags(write=False)
         setattr(self, name, arr)
+        if name == "_d_safety" and getattr(self, "_deltas", None) is not None and not np.all(self._deltas <= arr):
+            self._set_const("_deltas", self._deltas, "_delta")       # keep Delta <= d_hat (the constructor's invariant)
         if self._alloc_done:
             t = getattr(self, tensor_name)
-            t.copy_(self._torch.as_tensor(arr, dtype=self._torch.float32))
+            t.copy_(self._torch.as_tensor(arr.copy(), dtype=self._torch.float32))
             self._params_cache = None
 
     deltas = property(lambda self: self._deltas, lambda self, v: self._set_const("_deltas", v, "_delta"))
@@ -225,6 +242,15 @@ class drones:
         self.n_coll = torch.zeros(E, dtype=torch.int32, device=dev)
         self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
         self._act = torch.zeros(E, N, 2, **f32)
+        # terminal observation / state of the envs an auto-reset launch finishes (DroneEpisodeCtl.z_final ...)
+        self.z_final = torch.zeros(E, N, K1 * c, **f32) if self.keep_final_obs else None
+        self.nbr_final = torch.full((E, N, K1), -1, dtype=torch.int32, device=dev) if self.keep_final_obs else None
+        self.pos_final = torch.zeros(E, N, 2, **f32) if self.keep_final_obs else None
+        # the env's own output buffers; step(..., into=(storage, t)) re-binds the attributes to storage slots
+        self._home = dict(reward=self.reward, true_reward=self.true_reward, z=self.z, nbr_idx=self.nbr_idx,
+                          n_coll=self.n_coll, done=self.done, z_final=self.z_final, nbr_final=self.nbr_final,
+                          pos_final=self.pos_final)
+        self._bound_home = True
         self._params_cache = None
         self._step_args = None
         # episode bookkeeping (include/dronesim.h: DroneEpisodeAcc, one 64-byte record per env) -- off unless asked for
@@ -235,6 +261,7 @@ class drones:
         self.state = DroneState(self.pos, self.vel, self._radius) if self.batched else None
         # step() hands back the same live tensors every call
         self._result = StepResult(self.state, self.z, self.reward, self.n_coll, self.done, self.true_reward)
+        self._home["_result"] = self._result
 
     def _params(self):
         """DroneParams for this launch (collision_weight is live: train_problem.py:31)."""
@@ -261,18 +288,36 @@ class drones:
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _make_ctl(self, z_final=None, nbr_final=None, pos_final=None):
+        """A DroneEpisodeCtl of this env with the given terminal-observation targets (device tensors or None)."""
+        c = self._native.DroneEpisodeCtl()
+        c.acc = self.episode_acc.data_ptr() if self.episode_acc is not None else None
+        c.auto_reset = 1 if self.auto_reset else 0
+        c.div_x, c.div_y = lattice_divisions(self.grid)
+        c.pitch = float(LATTICE_PITCH)
+        c.seed, c.env_base = self.seed, self.env_lo
+        c.episode = self.episode.data_ptr()
+        c.z_final = None if z_final is None else z_final.data_ptr()
+        c.nbr_final = None if nbr_final is None else nbr_final.data_ptr()
+        c.pos_final = None if pos_final is None else pos_final.data_ptr()
+        return c
+
     def _ctl(self):
         """DroneEpisodeCtl of this env (None when neither bookkeeping nor auto-reset is on)."""
         if self._ctl_cache is None:
-            c = self._native.DroneEpisodeCtl()
-            c.acc = self.episode_acc.data_ptr() if self.episode_acc is not None else None
-            c.auto_reset = 1 if self.auto_reset else 0
-            c.div_x, c.div_y = lattice_divisions(self.grid)
-            c.pitch = float(LATTICE_PITCH)
-            c.seed, c.env_base = self.seed, self.env_lo
-            c.episode = self.episode.data_ptr()
-            self._ctl_cache = c
+            h = self._home
+            self._ctl_cache = self._make_ctl(h["z_final"], h["nbr_final"], h["pos_final"])
         return self._ctl_cache
+
+    def _bind(self, views, home):
+        """Point the observation / per-step output attributes at `views` (the env's own buffers or a storage slot)."""
+        self.reward, self.true_reward, self.z, self.nbr_idx = views["reward"], views["true_reward"], views["z"], views["nbr_idx"]
+        self.n_coll, self.done = views["n_coll"], views["done"]
+        self.z_final, self.nbr_final, self.pos_final = views["z_final"], views["nbr_final"], views["pos_final"]
+        self._result = views.get("_result") or StepResult(self.state, self.z, self.reward, self.n_coll, self.done,
+                                                          self.true_reward)
+        views["_result"] = self._result
+        self._bound_home = home
 
     @property
     def _use_ctl(self):
@@ -328,8 +373,15 @@ class drones:
                                         None if mask is None else mask.data_ptr(), self.n_envs, self._stream())
         self._native.check(rc, "dronesim_observe")
 
-    def step(self, actions, copy=False):
+    def step(self, actions, copy=False, into=None):
         """One env.step() for every env (drone_env.py:214-258).
+
+        ``into=(storage, t)`` (batched mode; a `rollout_buffer.RolloutStorage`): the launch writes every per-step
+        output STRAIGHT into slot ``t`` of the storage -- reward / true_reward / n_coll / done at ``[t]``, the new
+        observation at ``[t + 1]`` of its observation ring (so that ``storage.z_pre[t + 1]`` is already in place), the
+        terminal observation of finishing envs at ``z_final[t]`` -- with no extra launch or copy; the env's observation
+        attributes (``z``, ``nbr_idx``, ...) are re-bound to those slots.  T such calls with T distinct slots can be
+        captured in one hipGraph.
 
         Compat mode (E == 1): ``actions`` is any indexable of N array-likes ``[2]`` (list or deque);
         returns ``(state, z_states, r_vec, n_collisions, finished, true_r_vec)`` in the reference's
@@ -357,14 +409,27 @@ class drones:
             self._act.copy_(torch.from_numpy(a).view(1, self.n_agents, 2), non_blocking=False)
             act = self._act
         p = self._params()
-        # host fast path: the buffer addresses never change, so the argument list is built once;
-        # only the action pointer and the current stream vary per call
-        args = self._step_args
-        if args is None:
-            args = self._step_args = [C.byref(p), C.byref(self._ctl()) if self._use_ctl else None] + [
-                C.c_void_p(t.data_ptr()) for t in (
-                    self.pos, self.vel, self.t, self._act, self.reward, self.true_reward, self.z, self.nbr_idx,
-                    self.n_coll, self.done)] + [self.n_envs, None]
+        # host fast path: the buffer addresses never change, so the argument list is built once (per storage slot
+        # when stepping into a RolloutStorage); only the action pointer and the current stream vary per call
+        if into is not None:
+            if not self.batched:
+                raise ValueError("step(into=...) needs the batched (tensor) API")
+            storage, slot = into
+            args, views = storage._slot(self, int(slot))
+            av = views["actions"]
+            if av is not None and act.data_ptr() != av.data_ptr():
+                av.copy_(act)                                # (a policy writing into storage.actions[t] avoids this)
+            self._bind(views, home=False)
+        else:
+            if not self._bound_home:
+                self._bind(self._home, home=True)
+            args = self._step_args
+            if args is None:
+                h = self._home
+                args = self._step_args = [C.byref(p), C.byref(self._ctl()) if self._use_ctl else None] + [
+                    C.c_void_p(t.data_ptr()) for t in (
+                        self.pos, self.vel, self.t, self._act, h["reward"], h["true_reward"], h["z"], h["nbr_idx"],
+                        h["n_coll"], h["done"])] + [self.n_envs, None]
         args[0] = C.byref(p)
         args[5] = C.c_void_p(act.data_ptr())
         if torch.cuda.current_device() == self.device.index:
@@ -518,6 +583,7 @@ class drones:
         self.seed = int(state["seed"])
         self._ctl_cache = None
         self._step_args = None
+        self._ctl_generation = getattr(self, "_ctl_generation", 0) + 1    # storages re-build their per-slot ctls
         self.episode.copy_(torch.as_tensor(state["episode"], dtype=torch.int32).reshape(self.n_envs))
         if self.episode_acc is not None and "episode_acc" in state:
             self.episode_acc.copy_(torch.as_tensor(state["episode_acc"], dtype=torch.float64).reshape(self.n_envs, 8))
@@ -539,18 +605,23 @@ class drones:
                     episodes=ai[:, 6], done_return=a[:, 4] / N, done_true_return=a[:, 5] / N,
                     done_collisions=al[:, 6], done_len=al[:, 7])
 
-    def episode_totals(self):
+    def episode_totals(self, out=None):
         """One launch (`dronesim_episode_reduce`, fixed summation order): float64 ``[8]`` device tensor of this
         rank's sums (done_return, done_true_return, done_collisions, done_len, episodes, ep_return, ep_true_return,
         ep_len) with the returns summed over agents (divide by N for the reference's per-step mean).  This vector is
-        what multi-GPU runs all-gather (`sharding.EpisodeStats.reduce_env`)."""
+        what multi-GPU runs all-gather (`sharding.reduce_episode_records`).  ``out``: a float64 ``[8]`` device tensor
+        to reduce into (e.g. one slot of a ring when several reductions are captured in one hipGraph)."""
         if self.episode_acc is None:
             raise RuntimeError("construct the env with track_episodes=True (or auto_reset=True)")
+        dst = self._episode_totals if out is None else out
+        if out is not None and not (out.dtype == self._torch.float64 and out.numel() == 8 and out.device == self.device
+                                    and out.is_contiguous()):
+            raise ValueError("out must be a contiguous float64 [8] tensor on the env's device")
         with self._torch.cuda.device(self.device):
             rc = self._lib.dronesim_episode_reduce(self.episode_acc.data_ptr(), self.n_envs,
-                                                   self._episode_totals.data_ptr(), self._stream())
+                                                   dst.data_ptr(), self._stream())
         self._native.check(rc, "dronesim_episode_reduce")
-        return self._episode_totals
+        return dst
 
     # ------------------------------------------------------------------ compat-mode host views
     def _sync_host_views(self):

@@ -118,7 +118,7 @@ def stack_reference_modules(modules, kind=None):
 
 def pack_split_streams(w1, w2, w3, stages, scheme="bf16x3"):
     """The weight image of `dronesim_mlp_forward_bf16x3` / `_f16x2` (include/dronesim.h): per (agent, wave) one
-    stream of `stages` stages -- the P parts' fragments of one (chunk, k-step), 1 KiB each -- in the kernel's
+    stream of `stages` stages -- the P parts' fragments of one (chunk, k-step): P x 1 KiB per stage (3 KiB for bf16x3, 2 KiB for f16x2) -- in the kernel's
     consumption order.  Returns ``[N, 4, stages, P, 64, 8]`` bf16 (P = 3) or float16 (P = 2)."""
     import torch
     n, _, h1 = w1.shape
@@ -234,20 +234,33 @@ class BatchedMLP:
         return cls(*stack_reference_modules(load_reference_modules(path)), **kw)
 
     # ------------------------------------------------------------------ evaluation
-    def _run(self, z, want_out, sample, env_base=0, env=None):
+    def _given(self, t, shape, dtype, what):
+        """A caller-provided output tensor (e.g. a slot of a `RolloutStorage`): the kernel writes straight into it."""
+        torch = self._torch
+        if not (torch.is_tensor(t) and t.device == self.device and t.dtype == dtype and t.is_contiguous()
+                and t.numel() == int(torch.Size(shape).numel())):
+            raise ValueError(f"{what} must be a contiguous {dtype} tensor of {tuple(shape)} elements on {self.device}")
+        return t
+
+    def _run(self, z, want_out, sample, env_base=0, env=None, out=None, act_out=None, idx_out=None):
         torch = self._torch
         z = z.to(device=self.device, dtype=torch.float32).contiguous()
         E = z.shape[0]
         if tuple(z.shape[:2]) != (E, self.n_agents) or z[0, 0].numel() != self.d_in:
             raise ValueError(f"z must be [E,{self.n_agents},{self.d_in}], got {tuple(z.shape)}")
-        out = torch.empty(E, self.n_agents, self.nout, device=self.device) if want_out else None
+        if out is not None:
+            out = self._given(out, (E, self.n_agents, self.nout), torch.float32, "out")
+        elif want_out:
+            out = torch.empty(E, self.n_agents, self.nout, device=self.device)
         act = idx = None
         m = self._m
         m.sample_kind = self.sample_kind if sample else SAMPLE_NONE
         if sample:
-            act = torch.empty(E, self.n_agents, 2, device=self.device)
+            act = (torch.empty(E, self.n_agents, 2, device=self.device) if act_out is None
+                   else self._given(act_out, (E, self.n_agents, 2), torch.float32, "act_out"))
             if self.sample_kind == SAMPLE_CATEGORICAL:
-                idx = torch.empty(E, self.n_agents, dtype=torch.int32, device=self.device)
+                idx = (torch.empty(E, self.n_agents, dtype=torch.int32, device=self.device) if idx_out is None
+                       else self._given(idx_out, (E, self.n_agents), torch.int32, "idx_out"))
         entry = {"bf16": self._lib.dronesim_mlp_forward_bf16, "bf16x3": self._lib.dronesim_mlp_forward_bf16x3,
                  "f16x2": self._lib.dronesim_mlp_forward_f16x2,
                  "f32": self._lib.dronesim_mlp_forward}[self.precision]
@@ -263,16 +276,18 @@ class BatchedMLP:
             self.counter += 1
         return out, act, idx
 
-    def forward(self, z):
-        """Post-activation outputs ``[E,N,nout]``: action probabilities / (mu_x, mu_y, var_x, var_y) / value."""
-        return self._run(z, True, False)[0]
+    def forward(self, z, out=None):
+        """Post-activation outputs ``[E,N,nout]``: action probabilities / (mu_x, mu_y, var_x, var_y) / value.
+        ``out``: write them into this tensor (e.g. ``storage.values[t]`` for a critic: ``[E,N]`` = ``[E,N,1]``)."""
+        return self._run(z, True, False, out=out)[0]
 
-    def sample_action(self, z, env_base=0, return_outputs=False, env=None):
+    def sample_action(self, z, env_base=0, return_outputs=False, env=None, act_out=None, idx_out=None):
         """Batched ``sample_action`` (utils.py:304-309 / 110-117): actions ``[E,N,2]`` ready for ``env.step``;
         for the categorical policy also the chosen indices.  Every call advances the Philox counter; with
         ``env=`` (a batched `drones`) the stream is keyed by the env's own device-side ``t`` / ``episode``
-        counters instead, which keeps a captured hipGraph drawing fresh numbers on every replay."""
+        counters instead, which keeps a captured hipGraph drawing fresh numbers on every replay.
+        ``act_out`` / ``idx_out``: tensors the kernel writes the actions / indices into (``storage.actions[t]``)."""
         if env is not None:
             env_base = env.env_lo
-        out, act, idx = self._run(z, return_outputs, True, env_base, env)
+        out, act, idx = self._run(z, return_outputs, True, env_base, env, act_out=act_out, idx_out=idx_out)
         return (act, idx, out) if return_outputs else (act, idx)

@@ -84,7 +84,8 @@ def summarize_episodes(gathered, n_agents):
             "agent_steps": (float(tot[3]) + float(tot[7])) * n_agents,
             "mean_reward": (float(tot[0]) + float(tot[5])) / n_agents / max(float(tot[3]) + float(tot[7]), 1.0),
             "mean_true_reward": (float(tot[1]) + float(tot[6])) / n_agents / max(float(tot[3]) + float(tot[7]), 1.0),
-            "collisions_per_env_step": float(tot[2]) / max(float(tot[3]), 1.0),
+            # collisions are only totalled for COMPLETED episodes (done_collisions / done_len): named accordingly
+            "collisions_per_completed_env_step": float(tot[2]) / max(float(tot[3]), 1.0),
             "world_size": int(gathered.shape[0])}
 
 

@@ -112,9 +112,13 @@ def test_auto_reset_equals_step_then_masked_reset(torch, N, G, E, k, c):
     """auto_reset=True (reset + re-observation inside the step launch) is bit-identical to what the reference's
     loop does: step, then reset the envs whose `finished` fired (train_problem.py:82, 132): same fresh states
     (same Philox stream as dronesim_reset), same observation, same retired episode records."""
-    A = make_env(N, G, E, k=k, c=c, seed=21, auto_reset=True)
+    A = make_env(N, G, E, k=k, c=c, seed=21, auto_reset=True, keep_final_obs=True)
     B = make_env(N, G, E, k=k, c=c, seed=21, track_episodes=True)
     assert torch.equal(A.pos, B.pos)
+    # terminal observation (DroneEpisodeCtl.z_final / nbr_final / pos_final): rows of envs that have not finished in a
+    # launch must be left untouched -- tracked here from a recognisable fill
+    A.z_final.fill_(-7.0); A.nbr_final.fill_(-7); A.pos_final.fill_(-7.0)
+    zf, nf, pf = A.z_final.clone(), A.nbr_final.clone(), A.pos_final.clone()
     # stagger the time limit over the envs so that resets hit different envs at different steps, and drive a third
     # of the envs with the P-controller so that some finish by ARRIVAL (drone_env.py:251)
     t0 = (torch.arange(E, device="cuda:0", dtype=torch.int32) * 7) % 23 + 180
@@ -130,6 +134,10 @@ def test_auto_reset_equals_step_then_masked_reset(torch, N, G, E, k, c):
         rb = B.step(act, copy=True)
         done = rb.finished.bool()
         n_done += int(done.sum())
+        # what the reference's step() returns on the last call of an episode (drone_env.py:258) -- z-states, Ni and
+        # state of the FINAL state -- is what B holds before its reset, and what A's launch kept in *_final, bit for bit
+        zf[done] = rb.z_states[done]; nf[done] = B.nbr_idx[done]; pf[done] = rb.state.pos[done]
+        assert torch.equal(A.z_final, zf) and torch.equal(A.nbr_final, nf) and torch.equal(A.pos_final, pf), s
         if bool(done.any()):
             B.reset(renew_obstacles=False, mask=done)
         for name, x, y in (("reward", ra.rewards, rb.rewards), ("true_reward", ra.true_rewards, rb.true_rewards),

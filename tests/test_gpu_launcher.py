@@ -71,8 +71,28 @@ def test_bench_py_runs_with_two_ranks_on_one_device():
     assert out["steps"] == 30 and out["repeats"] >= 1 and out["timed_steps"] == 30 * out["graph_copies"] * out["repeats"]
     assert out["value"] == pytest.approx(64 * 1024 * out["timed_steps"] / out["timed_seconds"], rel=1e-9)
     st = out["episode_end_stats"]
-    assert st["world_size"] == 2 and st["exchanges_in_timed_region"] >= 1 and st["agent_steps"] > 0
+    assert st["world_size"] == 2 and st["agent_steps"] > 0
     assert st["mean_reward"] < 0 and out["roofline"]["frac"] > 0
+    # the exchange: one in-capture reduction per 200 steps, one collective per replay, and the line says a real one ran
+    ex = out["exchange"]
+    assert ex["real_collective_ran"] is True and ex["collectives_in_timed_region"] == out["repeats"]
+    assert ex["reduce_every_steps"] == 200 and ex["reductions_in_timed_region"] == out["repeats"] * (out["timed_steps"] // out["repeats"] // 200)
+    assert ex["collective_latency_us"] > 0
+    # every launch this job issued is accounted for by the device-side episode records
+    assert out["launch_check"]["ok"] is True and out["launch_check"]["env_steps_recorded_all_ranks"] == \
+        out["launch_check"]["launches_issued_per_rank"] * 1024
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["step_kernel_ms"] > 0 and r["envs"] == 512 for r in out["per_rank"])
+
+
+def test_bench_py_strong_scaling_splits_one_job():
+    """--scaling strong: the workload's 8-GPU job (8 x envs-per-gpu) is ONE job split over the ranks that run."""
+    r = _launch(2, "bench.py", ["--gpus", 2, "--steps", 20, "--warmup", 2, "--envs-per-gpu", 64, "--min-seconds", 0.05,
+                                "--no-cpu-baseline", "--scaling", "strong"], extra_env=dict(BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["config"]["n_envs_total"] == 512 and out["config"]["envs_per_gpu"] == 256
+    assert out["value"] == pytest.approx(64 * 512 * out["timed_steps"] / out["timed_seconds"], rel=1e-9)
+    assert out["launch_check"]["ok"] is True
 
 
 def test_rccl_all_gather_in_a_world_of_one():

@@ -1,0 +1,163 @@
+"""GPU tests of the on-device experience storage (first half): `RolloutStorage` filled by the step
+launches themselves (`drones.step(act, into=(storage, t))` -> `dronesim_step_ex` with slot t's addresses), against what
+the reference's `ExperienceBuffers.append` holds (utils.py:232-253, called at train_problem.py:96)."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch
+
+
+def make_env(N, G, E, k=2, c=2, **kw):
+    from scalable_collision_avoidance_rl_amd import drones
+    return drones(N, 0, [G, G], "O", k_closest=k, deltas=np.ones(N), simplify_zstate=(c == 2), n_envs=E, batched=True,
+                  device="cuda:0", seed=kw.pop("seed", 11), **kw)
+
+
+def test_storage_holds_the_reference_experience_tuples(torch):
+    """Config C1's episode (tests/golden/episode_n5.npz: the reference's own env driven by its seeded softmax-16
+    policy) replayed through the storage, teacher-forced on the reference's states: every stored tuple
+    (z_state, action, reward, next_z, Ni, finished) equals what `ExperienceBuffers.append(z_states, actions, rewards,
+    new_z, Ni, finished)` received at train_problem.py:96 (utils.py:244-249)."""
+    from scalable_collision_avoidance_rl_amd.rollout_buffer import RolloutStorage
+    fx = H.load("episode_n5.npz")
+    N, T = 5, fx["act"].shape[0]
+    env = make_env(N, 5.0, 1)
+    env.collision_weight = float(fx["collision_weight"])
+    env.set_state(fx["state0"][None, :, 0:2], fx["state0"][None, :, 2:4], t=0)
+    st = RolloutStorage(env, T, actions=True).begin()
+    f32 = lambda a: torch.tensor(np.asarray(a, np.float32), device="cuda:0")
+    for t in range(T):
+        if t > 0:                                     # teacher forcing: continue from the reference's float64 state
+            env.pos.copy_(f32(fx["pos"][t - 1][None])); env.vel.copy_(f32(fx["vel"][t - 1][None]))
+        res = env.step(f32(fx["act"][t][None]), into=(st, t))
+        assert res.z_states.data_ptr() == st.zbuf[t + 1].data_ptr() == env.z.data_ptr()      # written in place
+        assert res.rewards.data_ptr() == st.reward[t].data_ptr()
+    torch.cuda.synchronize()
+    z_ref = np.concatenate([fx["z0"][None], fx["z"]], 0).reshape(T + 1, N, 6)
+    nbr_ref = np.concatenate([fx["nbr0"][None], fx["nbr_idx"]], 0)
+    for t in range(T):
+        for i in range(N):
+            e = st.experience(t, i)
+            H.assert_close(e.z_state, z_ref[t, i], f"z_state t={t} i={i}")                   # z_states[i].flatten()
+            H.assert_close(e.action, fx["act"][t, i], f"action t={t}")
+            H.assert_close(e.reward, fx["reward"][t, i], f"reward t={t}")
+            H.assert_close(e.next_z, z_ref[t + 1, i], f"next_z t={t} i={i}")                 # new_z[i].flatten()
+            assert e.Ni == [int(j) for j in nbr_ref[t, i] if j >= 0] and e.Ni[0] == i, (t, i)
+            assert e.finished == bool(fx["done"][t])
+    assert np.array_equal(st.nbr_pre.cpu().numpy()[:, 0], fx["nbr_idx_pre"])
+    assert np.array_equal(st.n_coll.cpu().numpy()[:, 0], fx["n_coll"])
+    # the learner-side scans straight off the storage (SAC_agents.py:304-307, 333-351) meet the reference's figures
+    gamma = float(fx["discount"])
+    G = st.returns(gamma)
+    H.assert_close(G.cpu().numpy()[:, 0], fx["mc_return"], "G vs reference")
+    V = f32(fx["critic_value"][:, None, :])
+    H.assert_close(st.advantage(V, gamma, G).cpu().numpy()[:, 0], fx["adv_weight"], "adv weight vs reference")
+
+
+@pytest.mark.parametrize("N,G,E,c", [(64, 28.0, 96, 2), (5, 5.0, 130, 2), (130, 130.0, 7, 2), (9, 8.0, 40, 5)])
+def test_storage_steps_equal_plain_steps_across_episode_ends(torch, N, G, E, c):
+    """Stepping into the storage is the same launch with other output addresses: bit-identical to plain `step()` calls
+    whose outputs are cloned by the caller, with auto_reset firing inside the window; `next_z()` is the observation
+    before the reset where an episode ended (the reference's `new_z`, drone_env.py:258) and the post-step one
+    elsewhere; the observation ring makes z_pre[t + 1] the post-step observation of step t with no copy."""
+    from scalable_collision_avoidance_rl_amd.rollout_buffer import RolloutStorage
+    T = 24
+    A = make_env(N, G, E, c=c, seed=3, auto_reset=True)
+    B = make_env(N, G, E, c=c, seed=3, auto_reset=True, keep_final_obs=True)
+    t0 = (torch.arange(E, device="cuda:0", dtype=torch.int32) * 5) % 17 + 185
+    A.t.copy_(t0); B.t.copy_(t0)
+    st = RolloutStorage(A, T).begin()
+    g = torch.Generator(device="cuda:0").manual_seed(8)
+    acts = torch.rand(T, E, N, 2, device="cuda:0", generator=g) * 2 - 1
+    ref = {k: [] for k in ("z_pre", "nbr_pre", "reward", "true_reward", "z", "nbr", "n_coll", "done", "next_z", "next_nbr")}
+    for t in range(T):
+        ref["z_pre"].append(B.z.clone()); ref["nbr_pre"].append(B.nbr_idx.clone())
+        st.actions[t].copy_(acts[t])
+        A.step(st.actions[t], into=(st, t))
+        r = B.step(acts[t], copy=True)
+        d = r.finished.bool()
+        ref["reward"].append(r.rewards); ref["true_reward"].append(r.true_rewards); ref["z"].append(r.z_states)
+        ref["nbr"].append(B.nbr_idx.clone()); ref["n_coll"].append(r.n_collisions); ref["done"].append(r.finished)
+        ref["next_z"].append(torch.where(d[:, None, None], B.z_final, r.z_states))
+        ref["next_nbr"].append(torch.where(d[:, None, None], B.nbr_final, B.nbr_idx))
+        assert torch.equal(A.pos, B.pos) and torch.equal(A.t, B.t) and torch.equal(A.z, B.z)
+    S = lambda k: torch.stack(ref[k])
+    assert int(S("done").sum()) >= E // 2
+    assert torch.equal(st.z_pre, S("z_pre")) and torch.equal(st.nbr_pre, S("nbr_pre"))
+    assert torch.equal(st.reward, S("reward")) and torch.equal(st.true_reward, S("true_reward"))
+    assert torch.equal(st.z, S("z")) and torch.equal(st.nbr_idx, S("nbr")) and torch.equal(st.actions, acts)
+    assert torch.equal(st.n_coll, S("n_coll")) and torch.equal(st.done, S("done"))
+    nz, nn = st.next_z()
+    assert torch.equal(nz, S("next_z")) and torch.equal(nn, S("next_nbr"))
+    assert torch.equal(A.episode_acc, B.episode_acc)
+    # second pass over the same storage: begin() rolls the last observation into slot 0 (one copy per T steps)
+    last = A.z.clone()
+    st.begin()
+    assert torch.equal(st.zbuf[0], last) and A.z.data_ptr() == st.zbuf[0].data_ptr()
+    # and a plain step afterwards goes back to the env's own buffers
+    A.step(acts[0]); B.step(acts[0])
+    assert A.z.data_ptr() == A._home["z"].data_ptr() and torch.equal(A.z, B.z) and torch.equal(A.reward, B.reward)
+
+
+def test_storage_window_in_one_graph_with_policy_and_critic(torch):
+    """obs -> critic -> policy -> step, T steps with T distinct slot address sets captured in ONE hipGraph: the policy
+    writes its actions into `storage.actions[t]`, the critic its values into `storage.values[t]`, the step its outputs
+    into slot t -- no copy kernels in the graph; replays continue the rollout (all counters live on the device) and
+    equal the same loop run eagerly with cloned outputs."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    from scalable_collision_avoidance_rl_amd.rollout_buffer import RolloutStorage
+    N, G, E, T = 64, 28.0, 64, 12
+    gp = torch.Generator().manual_seed(0)
+    rw = lambda *s: (torch.rand(*s, generator=gp) * 2 - 1) * 0.2
+    wa = [rw(N, 6, 48), rw(N, 48), rw(N, 48, 48), rw(N, 48), rw(N, 48, 16), rw(N, 16)]
+    wc = [rw(N, 6, 32), rw(N, 32), rw(N, 32, 32), rw(N, 32), rw(N, 32, 1), rw(N, 1)]
+
+    def build():
+        env = make_env(N, G, E, seed=5, auto_reset=True)
+        env.t.fill_(193)                                   # the time limit fires inside the first window
+        return env, BatchedMLP(*wa, 1, 1, device="cuda:0", seed=7), BatchedMLP(*wc, 0, 0, device="cuda:0")
+
+    env, actor, critic = build()
+    st = RolloutStorage(env, T, actions=True, values=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        st.begin()
+        for t in range(T):                                 # warm-up pass (also builds the per-slot argument lists)
+            critic.forward(env.z, out=st.values[t])
+            actor.sample_action(env.z, env=env, act_out=st.actions[t])
+            env.step(st.actions[t], into=(st, t))
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    env2, actor2, critic2 = build()
+    rec = {k: [] for k in ("z_pre", "values", "actions", "reward", "done")}
+    for rep in range(3):                                   # eager reference: three windows
+        for t in range(T):
+            rec["z_pre"].append(env2.z.clone()); rec["values"].append(critic2.forward(env2.z).squeeze(-1).clone())
+            a, _ = actor2.sample_action(env2.z, env=env2)
+            r = env2.step(a, copy=True)
+            rec["actions"].append(a.clone()); rec["reward"].append(r.rewards); rec["done"].append(r.finished)
+    W = lambda k, rep: torch.stack(rec[k][rep * T:(rep + 1) * T])
+    for k in ("z_pre", "values", "actions", "reward", "done"):          # the warm-up pass was window 0
+        assert torch.equal(getattr(st, k), W(k, 0)), k
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        st.begin()
+        for t in range(T):
+            critic.forward(env.z, out=st.values[t])
+            actor.sample_action(env.z, env=env, act_out=st.actions[t])
+            env.step(st.actions[t], into=(st, t))
+    for rep in (1, 2):
+        graph.replay(); torch.cuda.synchronize()
+        for k in ("z_pre", "values", "actions", "reward", "done"):
+            assert torch.equal(getattr(st, k), W(k, rep)), (rep, k)
+    assert int(st.done.sum()) == 0 and int(W("done", 0).sum()) == E      # every env ended its episode in window 0
