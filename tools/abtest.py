@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Developer A/B harness: several builds of libdronesim.so against each other on one box, interleaved over rounds
+(box clocks drift by several percent between calls, so only same-call, interleaved comparisons mean anything).
+
+    python tools/abtest.py <rounds> <cases> lib_a.so lib_b.so ...
+    cases: comma list of  c3 (plain step) | c3e (step, episode layer + auto-reset: the graded kernel) | c3r (fused rollout)
+           | c3rr (fused rollout, actions drawn in the kernel, episode layer) | c5 | c5e | c5r | c2 | NxE:G:delta[e|r]
+
+Every (round, library) runs in its own process (the library is chosen at import time through DRONESIM_LIB)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def one(cases):
+    sys.path.insert(0, ROOT)
+    import torch
+    from scalable_collision_avoidance_rl_amd import drones
+    from tools.kbench import PRESETS
+    out = {}
+    for case in cases:
+        mode = "plain"
+        spec = case
+        for suffix, m in (("rr", "rollout_random"), ("r", "rollout"), ("e", "epi")):
+            if spec.endswith(suffix) and (spec[:-len(suffix)] in PRESETS or ":" in spec):
+                spec, mode = spec[:-len(suffix)], m
+                break
+        if spec in PRESETS:
+            N, E, G, delta = PRESETS[spec]
+        else:
+            ne, G, delta = spec.split(":")
+            N, E = (int(x) for x in ne.split("x")); G, delta = float(G), float(delta)
+        kw = dict(auto_reset=True) if mode in ("epi", "rollout_random") else {}
+        env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1, **kw)
+        g = torch.Generator(device="cuda").manual_seed(0)
+        T = 200
+        ts = []
+        if mode in ("plain", "epi"):
+            pool = torch.rand(T, E, N, 2, device="cuda", generator=g) * 2 - 1
+            for s in range(10):
+                env.step(pool[s])
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for s in range(T):
+                    env.step(pool[s])
+            graph.replay(); torch.cuda.synchronize()
+            for _ in range(12):
+                env.reset(renew_obstacles=False)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); graph.replay(); b.record(); torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) / T * 1e3)
+            del graph, pool
+        else:
+            act = None if mode == "rollout_random" else torch.rand(T, E, N, 2, device="cuda", generator=g) * 2 - 1
+            run = (lambda: env.rollout_random(T)) if act is None else (lambda: env.rollout(act))
+            o = run(); torch.cuda.synchronize(); del o
+            for _ in range(6):
+                env.reset(renew_obstacles=False)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); o = run(); b.record(); torch.cuda.synchronize(); del o
+                ts.append(a.elapsed_time(b) / T * 1e3)
+        out[case] = float(np.median(ts))
+        del env
+        torch.cuda.empty_cache()
+    print("ABTEST " + json.dumps(out), flush=True)
+
+
+def main():
+    if sys.argv[1] == "--one":
+        return one(sys.argv[2].split(","))
+    rounds, cases, libs = int(sys.argv[1]), sys.argv[2], sys.argv[3:]
+    res = {lib: {c: [] for c in cases.split(",")} for lib in libs}
+    for r in range(rounds):
+        for lib in libs:
+            env = dict(os.environ, DRONESIM_LIB=os.path.abspath(lib))
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--one", cases], env=env, capture_output=True,
+                               text=True, timeout=600)
+            line = [l for l in p.stdout.splitlines() if l.startswith("ABTEST ")]
+            if not line:
+                print(f"!! {lib} round {r}: no result\n{p.stderr[-1500:]}", flush=True)
+                continue
+            for c, v in json.loads(line[0][7:]).items():
+                res[lib][c].append(v)
+    base = libs[0]
+    print(f"{'library':<42}" + "".join(f"{c:>22}" for c in cases.split(",")))
+    for lib in libs:
+        row = f"{os.path.basename(lib):<42}"
+        for c in cases.split(","):
+            v, b = res[lib][c], res[base][c]
+            if not v:
+                row += f"{'--':>22}"
+                continue
+            m = float(np.median(v))
+            rel = "" if lib == base or not b else f" ({(m / float(np.median(b)) - 1) * 100:+.1f}%)"
+            row += f"{m:>13.3f}{rel:>9}"
+        print(row, flush=True)
+    print("us per step, median over rounds of per-process medians; rounds:", rounds)
+    for lib in libs:
+        print(os.path.basename(lib), {c: ["%.3f" % x for x in v] for c, v in res[lib].items()})
+
+
+if __name__ == "__main__":
+    main()
