@@ -240,6 +240,39 @@ __device__ __forceinline__ void st_out2(float *p, float x, float y)
     st_out(reinterpret_cast<f32x2 *>(p), v);
 }
 
+// LDS addresses as plain 32-bit integers: a value that is to be formed EARLY (ahead of the state loads' return) and
+// kept opaque with an empty asm must not be a generic pointer, or every access through it turns into a flat access
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2;
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
+}
+
+// Global-memory pointers that pass through an empty asm (to pin them in scalar registers early) must carry their address
+// space in the type: a generic pointer that comes out of an asm is accessed with FLAT instructions (64-bit per-lane
+// addresses, and an lgkmcnt count on every store).
+typedef __attribute__((address_space(1))) float g_f32;
+typedef __attribute__((address_space(1))) f32x2 g_f32x2;
+typedef __attribute__((address_space(1))) int g_i32;
+typedef __attribute__((address_space(1))) unsigned g_u32;
+typedef __attribute__((address_space(1))) uint8_t g_u8;
+typedef __attribute__((address_space(1))) u32x4 g_u32x4;
+template <typename T> __device__ __forceinline__ void st_g(__attribute__((address_space(1))) T *p, T v)
+{
+#if defined(DRONESIM_PLAIN_STORES)
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+__device__ __forceinline__ void st_g2(g_f32 *p, float x, float y)
+{
+    f32x2 v; v.x = x; v.y = y;
+    st_g((g_f32x2 *)p, v);
+}
+
 // @phase h_copy_out
 // Cooperative copy of `n` 4-byte words from a wave's LDS staging area to global memory: 16 bytes per
 // lane when the destination is 16-byte aligned (full 128-B lines, 1 KiB per wave-instruction),
@@ -421,6 +454,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         if (masked && valid) valid = a.mask[env] != 0;
     }
     const size_t step_agents = (size_t)a.E * N;              // rollout: per-step output stride
+    // all agents share d_hat, Delta and radius (host-known): the constants are kernel-argument scalars.  kSym64 is only
+    // chosen for such envs (launch()), so that its constants are wave-uniform at compile time: no per-agent loads, whose
+    // return the early (hoisted) uses would otherwise wait for behind the state loads
+    const bool uniform = SYM || a.uniform != 0;
 
     // @phase loads
     // ---- longest-latency loads first: this agent's state (HBM), then the shared constants (L2)
@@ -475,7 +512,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 tcur = a.t[env];
             }
 #if !defined(DRONESIM_ABL_NOACCIO)
-            if (has_acc && agent < 2)
+            if (has_acc && agent < 2)                        // (read ahead of the hoisted bases: its address is formed in place)
                 accw = *reinterpret_cast<const uint4 *>(a.acc + 8 * (size_t)env + 2 * agent);
 #endif
         }
@@ -484,7 +521,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             const float2 gl = reinterpret_cast<const float2 *>(a.xF_lo)[(unsigned)agent];
             xLx = gl.x; xLy = gl.y;
         }
-        if (a.uniform) {
+        if (uniform) {
             dhat = a.dhat_u; delta_i = a.delta_u; li = a.radius_u;
         } else {
             dhat = a.d_hat[(unsigned)agent];
@@ -494,6 +531,35 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         xi = p.x; yi = p.y;
         xFx = g.x; xFy = g.y;
     }
+
+    // @phase hoist
+    // ---- What the epilogue needs from the kernel arguments, and this wave's output bases, are fetched / formed HERE, in
+    // the shadow of the state loads (~2000 cycles during which the wave has nothing else to do).  Left to the compiler,
+    // each scalar load and each 64-bit base addition sits next to its first use -- behind the loads' return, on the
+    // wave's critical path, where every instruction costs the launch time (a lone wave issues one instruction per
+    // ~9 cycles, tools/ubench_valu.hip).  The empty asm statements make the values opaque at this point, so they
+    // cannot be re-materialised or sunk.  All of them are wave-uniform (scalar registers).
+    constexpr int kZRow = 2 * (K + 1), kNRow = K + 1;        // words per agent in the c = 2 layout
+    const bool w_reward = a.reward != nullptr, w_true = a.true_reward != nullptr, w_ncoll = a.n_coll != nullptr;
+    g_f32 *o_reward = (g_f32 *)(a.reward + wga0), *o_true = (g_f32 *)(a.true_reward + wga0);   // (dereferenced only under w_*)
+    g_f32 *o_pos = (g_f32 *)(a.pos + 2 * wga0), *o_vel = (g_f32 *)(a.vel + 2 * wga0);
+    g_u32 *o_gz = (g_u32 *)(reinterpret_cast<unsigned *>(a.z) + wga0 * kZRow);      // staged (c = 2) rows of this wave's agents
+    g_u32 *o_gn = (g_u32 *)(reinterpret_cast<unsigned *>(a.nbr_idx) + wga0 * kNRow);
+    float k_q = a.q, k_b = a.b, k_ghost = a.ghost_factor, k_done_radius = a.done_radius;
+    int k_last_t = a.max_steps - 1;
+    // one env per wave: the per-env words have scalar addresses too
+    g_i32 *o_ncoll = (g_i32 *)(a.n_coll + (SYM ? env0 : 0));
+    g_u8 *o_done = (g_u8 *)(a.done + (SYM ? env0 : 0));
+    g_i32 *o_t = (g_i32 *)(a.t + (SYM ? env0 : 0));
+    g_u32x4 *o_acc = (g_u32x4 *)(a.acc + 8 * (size_t)(SYM ? env0 : 0));
+    // (kSym64 only for now: the workgroup-per-env kernels of the episode layer sit at 85 scalar registers without them)
+    if (SYM && MODE != kObserve)
+        asm volatile("" : "+s"(o_reward), "+s"(o_true), "+s"(o_pos), "+s"(o_vel), "+s"(o_gz), "+s"(o_gn),
+                          "+s"(k_q), "+s"(k_b), "+s"(k_ghost), "+s"(k_done_radius), "+s"(k_last_t));
+    else if (SYM)
+        asm volatile("" : "+s"(o_reward), "+s"(o_true), "+s"(o_gz), "+s"(o_gn), "+s"(k_q), "+s"(k_b), "+s"(k_ghost));
+    if (SYM && MODE != kObserve) asm volatile("" : "+s"(o_ncoll), "+s"(o_done), "+s"(o_t));
+    if (SYM && EPI) asm volatile("" : "+s"(o_acc));
 
     // @phase lds_setup
     // ---- LDS carve-up (all region sizes multiples of 16 bytes); wave-local geometries give every wave
@@ -507,14 +573,18 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     int *sred = reinterpret_cast<int *>(sconst_all + (size_t)nconst * (N + (N & 1)));      // [epb][2]
     const int nred = 2 * a.epb + ((2 * a.epb) & 3 ? 4 - ((2 * a.epb) & 3) : 0);
     unsigned *sstage = reinterpret_cast<unsigned *>(sred + nred);
-    constexpr int kZRow = 2 * (K + 1), kNRow = K + 1;        // words per agent in the c = 2 layout
     unsigned *stage_z = sstage + (size_t)wave * kWave * (kZRow + kNRow);                   // [64][kZRow]
     unsigned *stage_n = stage_z + kWave * kZRow;                                           // [64][kNRow]
     float2 *sconst = sconst_all + (WL ? (size_t)wave * (N + (N & 1)) : 0);
     // bucket filter tables.  kSym64: per wave, cell -> lane mask, entries -1..64 of (x mask, y mask).
     // Other geometries: per env slot, [axis][W words of 64 agents][64 cells].
     unsigned long long *sbt_all = reinterpret_cast<unsigned long long *>(sstage + (size_t)nwaves * kWave * (kZRow + kNRow));
-    ulonglong2 *sbucket = reinterpret_cast<ulonglong2 *>(sbt_all) + (size_t)wave * kBucketRows + 1;
+    // kSym64: [x | y][64 cells] masks of 8 bytes per wave.  Agents live in cells 1..62 (coordinates beyond clamp to the
+    // end cells, which only adds candidates), so cells 0 and 63 stay empty: every lane zeroes its own entry of either
+    // table and reads cells c-1, c, c+1 without a guard row or an edge test.  (Round 2 kept (x, y) pairs at a 16-byte
+    // stride: cells c and c + 8 then shared their banks -- 2-3 way conflicts on the ds_or / ds_read of every launch,
+    // 40 % of the kernel's LDS cycles; at 8 bytes per cell the 23 cells of C3 are conflict-free.)
+    unsigned long long *sbx = sbt_all + (size_t)wave * (2 * kCells), *sby = sbx + kCells;
     const int W = BLOCKGEO ? nwaves : 1;
     const bool use_bucket = !FAR && !SYM && (BLOCKGEO || a.bucket != 0);                   // launch-uniform
     unsigned long long *sbt = sbt_all + (size_t)slot * (2 * kCells) * W;                   // this lane's env
@@ -525,21 +595,23 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 
     // (Delta_j, l_j) of a partner: kernel-argument scalars when all agents share them -- except in the fused
     // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
-    const bool uni_args = MODE != kRollout && a.uniform != 0;
+    const bool uni_args = MODE != kRollout && uniform;
     if (WL) {
         if (!SYM && (int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;   // kSym64 keeps these verdicts in scalar registers
         if (!uni_args && (int)lane < N)
-            sconst[lane] = a.uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[lane], a.radius[lane]);
+            sconst[lane] = uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[lane], a.radius[lane]);
     } else {
         if (tid < 2) sred[tid] = 0;
         if (!uni_args)
             for (int s = tid; s < N; s += blockDim.x)
-                sconst[s] = a.uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[s], a.radius[s]);
+                sconst[s] = uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[s], a.radius[s]);
     }
 
+    if (SYM && MODE != kRollout) { sbx[lane] = 0ull; sby[lane] = 0ull; }   // (the fused rollout zeroes them per rebuild)
+
     const float reach = SYM ? a.reach_max : dhat + li + a.radius_max;
-    const float thr = reach * reach * 1.000001f;             // early-out radius^2 (conservative)
-    const float log2_dhat = __builtin_amdgcn_logf(dhat);     // v_log_f32 = log2
+    float thr = reach * reach * 1.000001f;                   // early-out radius^2 (conservative)
+    float log2_dhat = __builtin_amdgcn_logf(dhat);           // v_log_f32 = log2
     float2 *spos_env = spos + (size_t)slot * 2 * stride;     // S0 of this lane's env
     // pass-1 window of this lane starts at dup index agent + (odd r): pick the copy where that is even
     const float2 *pwin = (agent & 1) ? spos_env + agent + 1 : spos_env + stride + agent + 2;
@@ -560,6 +632,20 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     const float inv_cell = __builtin_amdgcn_rcpf((CACHED ? reach + a.skin : a.reach_max) * 1.001f);   // bucket filter: cells a little wider than the list radius
     unsigned long long cand = 0ull;
     float refx = __builtin_nanf(""), refy = refx;            // NaN = no list yet
+    // self entry: d_ii = min(-2 l_i, dhat_i), ratio 1 -> log 0, never a collision (:323-325); N_delta[i,i] uses Delta_i (:346)
+    float dii = fminf(-li - li, dhat);
+    int in_range0 = ((dii <= delta_i) ? 1 : 0) - 1;
+    // this lane's slots of the wave's staging area (c = 2 rows leave through LDS as full lines): row of 2 (K+1) words of
+    // z, row of K+1 words of Ni, and the 16 bytes per lane and round of the copy-out
+    unsigned zrow_a = lds_addr(stage_z) + lane * (4 * kZRow), nrow_a = lds_addr(stage_n) + lane * (4 * kNRow);
+    unsigned copy_a = lds_addr(stage_z) + lane * 16;
+    // formed in the shadow of the state loads, like the scalar side above
+    unsigned long long self_bit = 1ull << lane;              // this lane's bit in the cell masks of the bucket filter
+    if (SYM) {
+        asm volatile("" : "+v"(thr), "+v"(log2_dhat), "+v"(dii), "+v"(in_range0), "+v"(zrow_a), "+v"(nrow_a), "+v"(copy_a),
+                          "+v"(self_bit));
+        __builtin_amdgcn_sched_barrier(0);                   // nothing of the above sinks behind the first use of the state
+    }
 
     // @phase integrate
     for (int step = 0; step < nsteps; ++step) {
@@ -626,10 +712,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         // partners reach pass 2 in ascending agent order on every path of these geometries (bucket / symmetric filter)
         constexpr bool ASC = SYM || (BLOCKGEO && !FAR);
         NbrList<K, ASC> list;
-        // self entry: d_ii = min(-2 l_i, dhat_i), ratio 1 -> log 0, never a collision (:323-325)
-        const float dii = fminf(-li - li, dhat);
-        list.init(dii, agent);
-        int in_range = ((dii <= delta_i) ? 1 : 0) - 1;        // :346 (N_delta[i,i] uses Delta_i), minus itself
+        list.init(dii, agent);                                // self entry (above)
+        int in_range = in_range0;                             // :346, minus itself
 
         // @phase pass2_visit
         // pass 2 body: the pair (this agent, partner at index jdup of the doubled position array)
@@ -735,7 +819,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 if (uni_args) walk(Defer{}, UniArgs{}); else walk(Defer{}, UniRuntime{});
                 if (__builtin_expect(list_degenerate(list), 0)) {
                     list.init(dii, agent);
-                    in_range = ((dii <= delta_i) ? 1 : 0) - 1;
+                    in_range = in_range0;
                     s_all = 0.f; s_msk = 0.f; ncoll = 0;
                     walk(NoDefer{}, UniRuntime{});
                 }
@@ -771,17 +855,16 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     //     (LDS atomics), then reads the three masks around its own cell per axis:
                     //     candidates = (x masks) & (y masks).  Coordinates beyond the 64 cells clamp to the end
                     //     cells, which only ever adds candidates.  ~35 instructions instead of 32 offsets x 5+.
-                    const unsigned long long self = 1ull << lane;
-                    sbucket[(int)lane] = make_ulonglong2(0ull, 0ull);
-                    if (lane < 2) sbucket[lane == 0 ? -1 : 64] = make_ulonglong2(0ull, 0ull);
-                    const int cx = (int)fminf(fmaxf(xi * inv_cell, 0.0f), 63.0f);
-                    const int cy = (int)fminf(fmaxf(yi * inv_cell, 0.0f), 63.0f);
+                    const unsigned long long self = self_bit;
+                    if (CACHED) { sbx[lane] = 0ull; sby[lane] = 0ull; }       // (step / observe: zeroed ahead of the loads' return)
+                    const int cx = (int)fminf(fmaxf(fmaf(xi, inv_cell, 1.0f), 1.0f), 62.0f);
+                    const int cy = (int)fminf(fmaxf(fmaf(yi, inv_cell, 1.0f), 1.0f), 62.0f);
                     group_sync<true>();
-                    atomicOr(&sbucket[cx].x, self);
-                    atomicOr(&sbucket[cy].y, self);
+                    atomicOr(&sbx[cx], self);
+                    atomicOr(&sby[cy], self);
                     group_sync<true>();
-                    unsigned long long pool = (sbucket[cx - 1].x | sbucket[cx].x | sbucket[cx + 1].x) &
-                                              (sbucket[cy - 1].y | sbucket[cy].y | sbucket[cy + 1].y) & ~self;
+                    unsigned long long pool = (sbx[cx - 1] | sbx[cx] | sbx[cx + 1]) &
+                                              (sby[cy - 1] | sby[cy] | sby[cy + 1]) & ~self;
                     unsigned long long hits = 0ull;          // bit j: agent j is inside the list radius
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_popcountll(pool) > kBucketMax) == 0ull, 1)) {
                         // (b) exact test of the few candidates
@@ -886,7 +969,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     }
                     if (__builtin_expect(list_degenerate(list), 0)) {
                         list.init(dii, agent);
-                        in_range = ((dii <= delta_i) ? 1 : 0) - 1;
+                        in_range = in_range0;
                         s_all = 0.f; s_msk = 0.f; ncoll = 0;
                         near = near0;
                         while (near) {
@@ -915,11 +998,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             // offset keeps float32 RELATIVE accuracy where the ghost direction and the arrival test are sensitive to it
             const float zx = (xi - xFx) - xLx, zy = (yi - xFy) - xLy;         // :357
             const float err2 = fmaf(zy, zy, zx * zx);
-            const float to_goal = a.q * err2;
-            r_out = -nan_to_num_f32(fmaf(a.b, s_msk, to_goal));
-            tr_out = -nan_to_num_f32(fmaf(a.b, s_all, to_goal));
-            if (a.reward) st_out(a.reward + so + wga0 + lane, r_out);
-            if (a.true_reward) st_out(a.true_reward + so + wga0 + lane, tr_out);
+            const float to_goal = k_q * err2;
+            r_out = -nan_to_num_f32(fmaf(k_b, s_msk, to_goal));
+            tr_out = -nan_to_num_f32(fmaf(k_b, s_all, to_goal));
+            if (w_reward) st_g(o_reward + so + lane, r_out);
+            if (w_true) st_g(o_true + so + lane, tr_out);
 #if defined(DRONESIM_ABL_NOSUM)
             if (false) {
 #else
@@ -930,7 +1013,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             }
 
             // localized state rows + neighbour list (:344-397)
-            const float gsc = __builtin_amdgcn_rsqf(err2) * delta_i * a.ghost_factor;
+            const float gsc = __builtin_amdgcn_rsqf(err2) * delta_i * k_ghost;
             const float ghx = zx * gsc, ghy = zy * gsc;                       // :386 (NaN when on the goal)
             zrx[0] = zx; zry[0] = zy; nbv[0] = agent;
             bool have[K + 1];
@@ -986,11 +1069,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             // @phase epilogue_state_done
             if (MODE != kObserve) {
                 if (MODE != kRollout || step == nsteps - 1) {                 // final state only
-                    st_out2(a.pos + 2 * wga0 + 2 * lane, xi, yi);
-                    st_out2(a.vel + 2 * wga0 + 2 * lane, vxi, vyi);
+                    st_g2(o_pos + 2 * lane, xi, yi);
+                    st_g2(o_vel + 2 * lane, vxi, vyi);
                 }
-                if (SYM) outside_m = __builtin_amdgcn_ballot_w64(!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius));
-                else if (!(__builtin_amdgcn_sqrtf(err2) <= a.done_radius)) atomicOr(&sred[2 * slot + 1], 1);   // :249-251
+                if (SYM) outside_m = __builtin_amdgcn_ballot_w64(!(__builtin_amdgcn_sqrtf(err2) <= k_done_radius));
+                else if (!(__builtin_amdgcn_sqrtf(err2) <= k_done_radius)) atomicOr(&sred[2 * slot + 1], 1);   // :249-251
             }
             if (SYM) {
                 // one env per wave: the env's collision count is a sum of ballot popcounts on the scalar unit (ballots of
@@ -1019,12 +1102,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #else
         if (staged && valid) {                                // this lane's rows -> the wave's staging area
 #endif
-            float2 *zrow = reinterpret_cast<float2 *>(stage_z) + lane * (K + 1);   // one base each, immediate offsets
-            unsigned *nrow = stage_n + lane * kNRow;
 #pragma unroll
-            for (int kth = 0; kth <= K; ++kth) zrow[kth] = make_float2(zrx[kth], zry[kth]);
+            for (int kth = 0; kth <= K; ++kth) {              // one base each (formed early), immediate offsets
+                f32x2 v; v.x = zrx[kth]; v.y = zry[kth];
+                *(lds_f32x2 *)(zrow_a + 8 * kth) = v;
+            }
 #pragma unroll
-            for (int kth = 0; kth <= K; ++kth) nrow[kth] = (unsigned)nbv[kth];
+            for (int kth = 0; kth <= K; ++kth) *(lds_u32 *)(nrow_a + 4 * kth) = (unsigned)nbv[kth];
         }
         TRACE_MARK(4);
         group_sync<WL>();
@@ -1038,12 +1122,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #else
         if (staged && nval > 0) {
 #endif
-            unsigned *gz = reinterpret_cast<unsigned *>(a.z) + (so + wga0) * kZRow;
-            unsigned *gn = reinterpret_cast<unsigned *>(a.nbr_idx) + (so + wga0) * kNRow;
+            g_u32 *gzg = o_gz + so * kZRow, *gng = o_gn + so * kNRow;
+            unsigned *gz = (unsigned *)gzg, *gn = (unsigned *)gng;              // (generic views for the ragged copy)
             // wave-uniform row bases: pinned in SGPRs so that the stores below address as scalar base + 32-bit lane
             // offset (the compiler otherwise builds 64-bit per-lane addresses: three v_lshl_add_u64 and two v_mad_i64_i32)
-            typedef __attribute__((address_space(1))) u32x4 gu32x4;   // (the asm would otherwise leave generic pointers)
-            gu32x4 *gz4 = (gu32x4 *)gz, *gn4 = (gu32x4 *)gn;
+            typedef g_u32x4 gu32x4;
+            gu32x4 *gz4 = (gu32x4 *)gzg, *gn4 = (gu32x4 *)gng;
             // fixed-shape copy: a full wave of agents whose rows start 16-byte aligned -- always for kSym64 (checked on
             // the host), every full wave of the workgroup-per-env geometries otherwise (wave-uniform test)
             const bool fixed = SYM || (BLOCKGEO && nval == kWave &&
@@ -1062,9 +1146,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 constexpr int rz = (nz + 4 * kWave - 1) / (4 * kWave), rn = (nn + 4 * kWave - 1) / (4 * kWave);
                 u32x4 vz[rz], vn[rn];
 #pragma unroll
-                for (int r = 0; r < rz; ++r) vz[r] = reinterpret_cast<const u32x4 *>(stage_z + r * 4 * kWave)[lane];
+                for (int r = 0; r < rz; ++r) vz[r] = *(const lds_u32x4 *)(copy_a + r * 16 * kWave);
 #pragma unroll
-                for (int r = 0; r < rn; ++r) vn[r] = reinterpret_cast<const u32x4 *>(stage_n + r * 4 * kWave)[lane];
+                for (int r = 0; r < rn; ++r) vn[r] = *(const lds_u32x4 *)(copy_a + 4 * nz + r * 16 * kWave);
 #pragma unroll
                 for (int r = 0; r < rz; ++r)
                     if ((r + 1) * 4 * kWave <= nz || (int)lane * 4 < nz - r * 4 * kWave)
@@ -1084,7 +1168,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             // one env per wave: verdicts are wave-uniform, the record update is branch-free (lane 0 holds the two sums,
             // lane 1 the counters), and lane 0's stores are the only masked region
             const int tc = MODE != kObserve ? __builtin_amdgcn_readfirstlane(tcur) : 0;      // lane 0 = agent 0
-            const bool fin = MODE != kObserve && (outside_m == 0ull || tc >= a.max_steps - 1);   // :251
+            const bool fin = MODE != kObserve && (outside_m == 0ull || tc >= k_last_t);   // :251
             fin_env = fin;
             if (has_acc) {                                        // train_problem.py:98-100 and t_iter, every step
                 const double nr = __builtin_bit_cast(double, make_uint2(accw.x, accw.y)) + (double)r_env;
@@ -1095,9 +1179,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                                   l0 ? w1.x : accw.z, l0 ? w1.y : accw.w);
             }
             if (lane == 0) {
-                const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
-                if (a.n_coll) a.n_coll[eo] = coll_s;
-                if (MODE != kObserve) a.done[eo] = (uint8_t)fin;
+                const size_t eo = (MODE == kRollout) ? (size_t)step * a.E : 0;
+                if (w_ncoll) o_ncoll[eo] = coll_s;
+                if (MODE != kObserve) o_done[eo] = (uint8_t)fin;
             }
         } else
         if (valid && (agent == 0 || (has_acc && agent == 1))) {
@@ -1108,7 +1192,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 if (a.n_coll) a.n_coll[eo] = coll_env;
                 bool fin = false;
                 if (MODE != kObserve) {
-                    fin = (red.y == 0) || (tcur >= a.max_steps - 1);                              // :251
+                    fin = (red.y == 0) || (tcur >= k_last_t);                                     // :251
                     a.done[eo] = (uint8_t)fin;
                     fin_env = fin;
                 }
@@ -1241,7 +1325,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
                 if (rs) {                                         //           have landed before they are overwritten
                     list.init(dii, agent);
-                    in_range = ((dii <= delta_i) ? 1 : 0) - 1;
+                    in_range = in_range0;
                     if (WMAX <= 4) {
                         // one cheap scan builds this agent's partner mask, then it walks its own bits: the expensive
                         // pair arithmetic runs max-over-lanes(partners) times, not once per agent of the env
@@ -1307,18 +1391,25 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         }
                     }
                     if (MODE != kRollout || step == nsteps - 1) {
-                        st_out2(a.pos + 2 * wga0 + 2 * lane, xi, yi);
-                        st_out2(a.vel + 2 * wga0 + 2 * lane, 0.f, 0.f);
+                        st_g2(o_pos + 2 * lane, xi, yi);
+                        st_g2(o_vel + 2 * lane, 0.f, 0.f);
                     }
                 }
             }
         }
         if (MODE == kRollout) group_sync<WL>();               // staging / sred reuse by the next step
     }
-    if (MODE != kObserve && valid && agent == 0) a.t[env] = tcur;
+    if (SYM) {                                                // scalar bases + lane offsets
+        if (MODE != kObserve && lane == 0) *o_t = tcur;
 #if !defined(DRONESIM_ABL_NOACCIO)
-    if (has_acc && valid && agent < 2) *reinterpret_cast<uint4 *>(a.acc + 8 * (size_t)env + 2 * agent) = accw;
+        if (has_acc && lane < 2) { u32x4 w; w.x = accw.x; w.y = accw.y; w.z = accw.z; w.w = accw.w; o_acc[lane] = w; }
 #endif
+    } else {
+        if (MODE != kObserve && valid && agent == 0) a.t[env] = tcur;
+#if !defined(DRONESIM_ABL_NOACCIO)
+        if (has_acc && valid && agent < 2) *reinterpret_cast<uint4 *>(a.acc + 8 * (size_t)env + 2 * agent) = accw;
+#endif
+    }
     TRACE_MARK(5);
 #if defined(DRONESIM_TRACE)
     __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): all stores acknowledged
@@ -1985,8 +2076,8 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
     a.bucket = (g.P > 0 && p->N >= kBucketMinN && !far) ? 1 : 0;
 #if !defined(DRONESIM_NO_SYM64)
-    if (p->N == 64 && !far && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
-        g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane
+    if (p->N == 64 && !far && a.uniform && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
+        g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane; uniform (d_hat, Delta, radius) only
 #endif
     hipStream_t s = static_cast<hipStream_t>(stream);
 #if DRONESIM_PART == 0
