@@ -153,6 +153,11 @@ template <int K> struct NbrList<K, false> {
     template <bool DEFER = false>
     __device__ __forceinline__ void insert(float d, int j, float) { nbr_insert<K>(key, nbr_key(d, j)); }
     __device__ __forceinline__ unsigned index(int kth) const { return (unsigned)key[kth]; }
+    __device__ __forceinline__ void pin()
+    {
+#pragma unroll
+        for (int s = 0; s <= K; ++s) asm volatile("" : "+v"(key[s]));
+    }
 };
 template <int K> struct NbrList<K, true> {
     float d[K + 1];
@@ -202,6 +207,12 @@ template <int K> struct NbrList<K, true> {
         }
     }
     __device__ __forceinline__ unsigned index(int kth) const { return j[kth]; }
+    // the entries as opaque register values at this point (see the hoisted block of drone_kernel)
+    __device__ __forceinline__ void pin()
+    {
+#pragma unroll
+        for (int s = 0; s <= K; ++s) asm volatile("" : "+v"(d[s]), "+v"(j[s]));
+    }
 };
 
 struct Defer { static constexpr bool value = true; };
@@ -380,6 +391,10 @@ __device__ __forceinline__ void group_sync()
 // EPI = true adds the episode bookkeeping of the *_ex entry points (DroneEpisodeCtl): per-env running sums, in-kernel
 // reset of finished envs, in-kernel random actions.  EPI = false is the plain step / observe / rollout: none of that
 // code exists in it.
+// byte offset of `rest` in drone_kernel's kernel-argument segment: two pointers + four ints in front of it
+constexpr int kKArgsOffset = 2 * 8 + 4 * 4;
+static_assert(kKArgsOffset % alignof(KArgs) == 0, "KArgs sits right behind the leading scalar arguments");
+
 template <int K, bool FAR, int MODE, int GEO, bool EPI>
 __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::kMinWavesPerSimd) drone_kernel(
     // The first 8 dwords of the kernel arguments are preloaded into SGPRs at wave launch (Makefile:
@@ -467,8 +482,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // episode bookkeeping (dronesim_*_ex): the running sums of an env's DroneEpisodeAcc record live in the registers
     // of its agent-0 lane for the whole launch; `epi` = resets the env has seen (stream id of reset and actions)
     static_assert(!(EPI && MODE == kObserve), "observe has no episode bookkeeping");
-    const bool has_acc = EPI && (epi_flags & 1) != 0;
-    const bool auto_reset = EPI && (epi_flags & 2) != 0;
+    // (kSym64: the word is made opaque so that every test is one s_bitcmp on it; as boolean values the compiler keeps
+    // them as 64-bit lane masks and spends a v_cndmask / v_cmp pair on each negation)
+    int epi_word = epi_flags;
+    if (SYM && EPI) asm volatile("" : "+s"(epi_word));
+#define has_acc (EPI && (epi_word & 1) != 0)
+#define auto_reset (EPI && (epi_word & 2) != 0)
     const bool rand_act = EPI && MODE == kRollout && (epi_flags & 4) != 0;
     // the 32 hot bytes of the env's record live in registers for the whole launch, split over two lanes so that one
     // load and one store instruction move them: agent 0 holds (ep_return, ep_true_return) as two doubles, agent 1
@@ -591,7 +610,6 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // tail (episode bookkeeping): per-wave partial reward sums [nwaves][2], then the sampling tables of the in-kernel
     // reset, [epb][samp_tbl] x (node, owner)
     float *spart = reinterpret_cast<float *>(smem + a.lds_tail);
-    int2 *ssamp = reinterpret_cast<int2 *>(spart + 2 * ((nwaves + 1) & ~1));
 
     // (Delta_j, l_j) of a partner: kernel-argument scalars when all agents share them -- except in the fused
     // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
@@ -641,9 +659,22 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     unsigned copy_a = lds_addr(stage_z) + lane * 16;
     // formed in the shadow of the state loads, like the scalar side above
     unsigned long long self_bit = 1ull << lane;              // this lane's bit in the cell masks of the bucket filter
+    // partners reach pass 2 in ascending agent order on every path of these geometries (bucket / symmetric filter)
+    constexpr bool ASC = SYM || (BLOCKGEO && !FAR);
+    // start values of pass 2 (row sums, collision count, the neighbour list holding the agent itself): in a single-step
+    // launch they are register values set up early as well -- as rematerialisable constants the compiler sets them twice
+    // on the critical path (once around and once inside the wave's "does any lane have a partner" branch)
+    NbrList<K, ASC> list0;
+    list0.init(dii, agent);
+    float sum0_all = 0.f, sum0_msk = 0.f;
+    int ncoll0 = 0;
     if (SYM) {
         asm volatile("" : "+v"(thr), "+v"(log2_dhat), "+v"(dii), "+v"(in_range0), "+v"(zrow_a), "+v"(nrow_a), "+v"(copy_a),
                           "+v"(self_bit));
+        if (MODE != kRollout) {
+            list0.pin();
+            asm volatile("" : "+v"(sum0_all), "+v"(sum0_msk), "+v"(ncoll0));
+        }
         __builtin_amdgcn_sched_barrier(0);                   // nothing of the above sinks behind the first use of the state
     }
 
@@ -707,12 +738,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         // @phase pass2_init
         float zrx[K + 1], zry[K + 1];
         int nbv[K + 1];
-        float s_all = 0.f, s_msk = 0.f;
-        int ncoll = 0;
-        // partners reach pass 2 in ascending agent order on every path of these geometries (bucket / symmetric filter)
-        constexpr bool ASC = SYM || (BLOCKGEO && !FAR);
-        NbrList<K, ASC> list;
-        list.init(dii, agent);                                // self entry (above)
+        float s_all = sum0_all, s_msk = sum0_msk;
+        int ncoll = ncoll0;
+        NbrList<K, ASC> list = list0;                         // holds the self entry
         int in_range = in_range0;                             // :346, minus itself
 
         // @phase pass2_visit
@@ -1235,13 +1263,26 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 any_rs = WL ? (__builtin_amdgcn_ballot_w64(rs) != 0ull) : (__builtin_amdgcn_readfirstlane((int)flag) != 0);
             }
             if (__builtin_expect(any_rs, 0)) {                // once per episode and env: out of line
+                // This block's own kernel arguments are read through the kernel-argument segment behind an opaque pointer,
+                // and its per-lane addresses are formed from an opaque copy of the lane id: read as fields of `a` / formed
+                // from `lane`, the compiler hoists those scalar loads and 64-bit additions in front of the branch, i.e.
+                // onto the critical path of EVERY step (six s_load and four vector instructions at C3)
+                const __attribute__((address_space(4))) char *kseg =
+                    (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+                unsigned lane_c = lane;
+                asm volatile("" : "+s"(kseg), "+v"(lane_c));
+                const __attribute__((address_space(4))) KArgs &ca =
+                    *(const __attribute__((address_space(4))) KArgs *)(kseg + kKArgsOffset);
+                int *const c_episode = ca.episode;
                 if (!rand_act && rs)                          // the episode counter is only needed here: read it now (past
-                    epi = (uint32_t)__builtin_nontemporal_load(a.episode + env);   // L1: an earlier reset of this launch wrote it)
-                if (rs && agent == 0) a.episode[env] = (int)(epi + 1u);
+                    epi = (uint32_t)__builtin_nontemporal_load(c_episode + env);   // L1: an earlier reset of this launch wrote it)
+                if (rs && agent == 0) c_episode[env] = (int)(epi + 1u);
                 // terminal state of the finished episode (drone_env.py:258 returns it; the reset below overwrites it)
-                if (rs && a.pos_final != nullptr) st_out2(a.pos_final + 2 * (so + wga0 + lane), xi, yi);
+                float *const c_pos_final = ca.pos_final, *const c_z_final = ca.z_final;
+                int *const c_nbr_final = ca.nbr_final;
+                if (rs && c_pos_final != nullptr) st_out2(c_pos_final + 2 * (so + wga0 + lane_c), xi, yi);
                 if (rs && has_acc && agent < 2) {                 // retire the finished episode (train_problem.py:118-121)
-                    double *tot = a.acc + 8 * (size_t)env + 4 + 2 * agent;        // agent 0: done_return, done_true_return
+                    double *tot = ca.acc + 8 * (size_t)env + 4 + 2 * agent;       // agent 0: done_return, done_true_return
                     if (agent == 0) {                                             // agent 1: done_collisions, done_len
                         const double2 dn = *reinterpret_cast<const double2 *>(tot);
                         *reinterpret_cast<double2 *>(tot) =
@@ -1259,8 +1300,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 // through an open-addressing table in LDS instead of an O(N) scan per agent: settled agents enter their
                 // node as blockers (owner -1), proposers enter theirs with owner = min(agent index); a proposer wins iff
                 // it owns its entry.  Keys are compared exactly, so the draw is the one reset_kernel / the oracle make.
-                const int nt = a.samp_tbl;                        // entries per env slot, a power of two >= 2 N
-                int2 *tbl = ssamp + (size_t)slot * nt;
+                const int nt = ca.samp_tbl;                       // entries per env slot, a power of two >= 2 N
+                const uint32_t c_key0 = ca.key0, c_key1 = ca.key1, c_lat_M = ca.lat_M;
+                const int c_shift = ca.samp_shift, c_div_y = ca.div_y;
+                const float c_pitch = ca.pitch;
+                // (the sampling tables sit behind the per-wave partial sums, see the LDS carve-up)
+                int2 *tbl = reinterpret_cast<int2 *>(reinterpret_cast<float *>(smem + ca.lds_tail) + 2 * ((nwaves + 1) & ~1)) + (size_t)slot * nt;
+                const uint32_t gid_c = ca.gid_base + (uint32_t)env;
                 int node = -1;
                 uint32_t round = 0;
                 bool more;
@@ -1275,8 +1321,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     int prop = node, h = 0;
                     if (rs) {
                         if (node < 0)
-                            prop = (int)__umulhi(philox4x32_10_word0((uint32_t)agent, round, gid, epi, a.key0, a.key1), a.lat_M);
-                        h = (int)(((uint32_t)prop * 0x9E3779B1u) >> a.samp_shift);
+                            prop = (int)__umulhi(philox4x32_10_word0((uint32_t)agent, round, gid_c, epi, c_key0, c_key1), c_lat_M);
+                        h = (int)(((uint32_t)prop * 0x9E3779B1u) >> c_shift);
                         for (;;) {                                                // linear probing, load factor <= 1/2
                             const int old = atomicCAS(&tbl[h].x, -1, prop);
                             if (old == -1 || old == prop) break;
@@ -1293,8 +1339,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 } while (more && round < (1u << 20));
                 if (rs) {
                     if (node >= 0) {                              // (an agent still unsettled after 2^20 rounds keeps its place)
-                        const int idx = node / a.div_y, jdx = node - idx * a.div_y;
-                        xi = (float)idx * a.pitch; yi = (float)jdx * a.pitch;     // drone_env.py:196-205
+                        const int idx = node / c_div_y, jdx = node - idx * c_div_y;
+                        xi = (float)idx * c_pitch; yi = (float)jdx * c_pitch;     // drone_env.py:196-205
                     }
                     vxi = 0.f; vyi = 0.f;                                         // :189
                     tcur = 0;                                                     // :100
@@ -1305,19 +1351,19 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
                 group_sync<WL>();
                 __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): this wave's earlier z / Ni / state stores
-                if (rs && (a.z_final != nullptr || a.nbr_final != nullptr)) {
+                if (rs && (c_z_final != nullptr || c_nbr_final != nullptr)) {
                     // terminal observation (the `new_z` of the episode's last transition, utils.py:244-249): this lane's
                     // rows of z / Ni as the hot path has just written them -- all of them by THIS wave, whose stores have
                     // been acknowledged above -- are read back past L1 and kept before the re-observation replaces them
-                    const size_t row = so + wga0 + lane;
-                    if (a.z_final != nullptr) {
+                    const size_t row = so + wga0 + lane_c;
+                    if (c_z_final != nullptr) {
                         const float *src = a.z + row * (size_t)((K + 1) * zc);
-                        float *dst = a.z_final + row * (size_t)((K + 1) * zc);
+                        float *dst = c_z_final + row * (size_t)((K + 1) * zc);
                         for (int w = 0; w < (K + 1) * zc; ++w) st_out(dst + w, __builtin_nontemporal_load(src + w));
                     }
-                    if (a.nbr_final != nullptr) {
+                    if (c_nbr_final != nullptr) {
                         const int *src = a.nbr_idx + row * (size_t)(K + 1);
-                        int *dst = a.nbr_final + row * (size_t)(K + 1);
+                        int *dst = c_nbr_final + row * (size_t)(K + 1);
 #pragma unroll
                         for (int w = 0; w <= K; ++w) st_out(dst + w, __builtin_nontemporal_load(src + w));
                     }
@@ -1365,8 +1411,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     }
                     const float zx = (xi - xFx) - xLx, zy = (yi - xFy) - xLy;
                     const float gsc = __builtin_amdgcn_rsqf(fmaf(zy, zy, zx * zx)) * delta_i * a.ghost_factor;
-                    float *zr = a.z + (so + wga0 + lane) * (size_t)((K + 1) * zc);
-                    int *nb = a.nbr_idx + (so + wga0 + lane) * (size_t)(K + 1);
+                    float *zr = a.z + (so + wga0 + lane_c) * (size_t)((K + 1) * zc);
+                    int *nb = a.nbr_idx + (so + wga0 + lane_c) * (size_t)(K + 1);
 #pragma unroll
                     for (int kth = 0; kth <= K; ++kth) {
                         const unsigned j = list.index(kth);
@@ -1391,8 +1437,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                         }
                     }
                     if (MODE != kRollout || step == nsteps - 1) {
-                        st_g2(o_pos + 2 * lane, xi, yi);
-                        st_g2(o_vel + 2 * lane, 0.f, 0.f);
+                        st_g2(o_pos + 2 * lane_c, xi, yi);
+                        st_g2(o_vel + 2 * lane_c, 0.f, 0.f);
                     }
                 }
             }
@@ -1410,6 +1456,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         if (has_acc && valid && agent < 2) *reinterpret_cast<uint4 *>(a.acc + 8 * (size_t)env + 2 * agent) = accw;
 #endif
     }
+#undef has_acc
+#undef auto_reset
     TRACE_MARK(5);
 #if defined(DRONESIM_TRACE)
     __builtin_amdgcn_s_waitcnt(0);          // vmcnt(0): all stores acknowledged
