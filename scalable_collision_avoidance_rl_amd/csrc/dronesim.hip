@@ -314,19 +314,26 @@ __device__ __forceinline__ float dpp_or_zero(float v)   // v of the lane CTRL se
 // 32-63 of `a` <-> lanes 0-31 of `b`) so that lanes 0-31 carry a[l] + a[l+32] and lanes 32-63 carry b[l-32] + b[l];
 // one DPP tree over the 32-lane halves (row_shr 1,2,3 -> quads, row_shr 4 / 8 -> rows, row_bcast 15 -> half) then
 // leaves sum(a) in lane 31 and sum(b) in lane 63.  The order of the additions is fixed: bit-reproducible.
+// Every stage is a full-mask DPP add through the compiler's own builtin (one v_add_f32_dpp each after its DPP
+// combine): lanes other than 15 / 31 / 63 of a row end up with partial sums nobody reads, and -- unlike the inline-asm
+// form of round 2, whose stages each carried their own s_nop -- the scheduler can fill the two wait states behind
+// every stage with the z-row arithmetic that surrounds the call (the chain is dependent; alone it is 8 idle slots).
 // (Tried on the matrix pipe instead -- two chained v_mfma_f32_16x16x4_f32 with B = ones per sum: +0.3 us per launch.)
-__device__ __forceinline__ float2 wave_sum64_pair(float a, float b)
+__device__ __forceinline__ float wave_sum64_tree(float a, float b)
 {
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     const float v = a + b;
     float t = v + dpp_or_zero<0x111, 0xf, 0xf>(v);
     t += dpp_or_zero<0x112, 0xf, 0xf>(v);
     t += dpp_or_zero<0x113, 0xf, 0xf>(v);
-    // the bank- / row-masked stages add in place (lanes outside the mask keep t): one instruction each -- through
-    // update_dpp the compiler spends three (zero the temporary, v_mov_dpp into it, add)
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(t));
+    t += dpp_or_zero<0x114, 0xf, 0xf>(t);                   // row_shr:4  (lane 15 of a row: + lanes 8..11's quad sum ...)
+    t += dpp_or_zero<0x118, 0xf, 0xf>(t);                   // row_shr:8
+    t += dpp_or_zero<0x142, 0xf, 0xf>(t);                   // row_bcast:15 (lane 15 of a row -> the next row)
+    return t;                                               // sum(a) in lane 31, sum(b) in lane 63
+}
+__device__ __forceinline__ float2 wave_sum64_pair(float a, float b)
+{
+    const float t = wave_sum64_tree(a, b);
     return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 31)),
                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63)));
 }
@@ -441,8 +448,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #if !defined(DRONESIM_NO_XCD_MAP)
     if (vb < xcd_blocks) vb = ((vb >> 8) << 8) + ((vb & 7u) << 5) + ((vb >> 3) & 31u);
 #endif
-    if (WL) {                                                // lane -> (env slot inside the wave, agent)
-        const int sub = SYM ? 0 : (int)lane / N;
+    if (SYM) {                                               // one env per wave: the shortest way to the first loads
+        slot = wave;
+        agent = (int)lane;
+        env0 = (int)vb * a.epb + wave;
+        nval = env0 < a.E ? kWave : 0;
+    } else if (WL) {                                         // lane -> (env slot inside the wave, agent)
+        const int sub = (int)lane / N;
         slot = wave * a.P + sub;
         agent = (int)lane - sub * N;
         env0 = (int)vb * a.epb + wave * a.P;
@@ -454,7 +466,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         nval = max(0, min(kWave, N - wave * kWave));
     }
     const size_t wga0 = (size_t)env0 * N + (WL ? 0 : wave * kWave);
-    const int env = env0 + (WL ? slot - wave * a.P : 0);
+    const int env = env0 + ((WL && !SYM) ? slot - wave * a.P : 0);
     const bool masked = MODE == kObserve && a.mask != nullptr;
     bool valid;
     if (SYM) {
@@ -1034,10 +1046,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #if defined(DRONESIM_ABL_NOSUM)
             if (false) {
 #else
-            if (SYM && has_acc) {                             // all 64 lanes are here (one env per wave): start the
-#endif
-                const float2 sm = wave_sum64_pair(r_out, tr_out);   // dependent chain now, the rows below overlap it
-                r_env = sm.x; tr_env = sm.y;
+            if (SYM && EPI) {                                 // all 64 lanes are here (one env per wave).  Not under the
+#endif                                                        // run-time `has_acc`: a branch would fence the dependent
+                const float2 sm = wave_sum64_pair(r_out, tr_out);   // chain off from the row arithmetic below, which fills
+                r_env = sm.x; tr_env = sm.y;                  // its wait states
             }
 
             // localized state rows + neighbour list (:344-397)
