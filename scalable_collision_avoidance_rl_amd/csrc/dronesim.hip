@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // (kSym64: the word is made opaque so that every test is one s_bitcmp on it; as boolean values the compiler keeps
     // them as 64-bit lane masks and spends a v_cndmask / v_cmp pair on each negation)
     int epi_word = epi_flags;
-    if (SYM && EPI) asm volatile("" : "+s"(epi_word));
+    if (SYM && EPI && MODE != kRollout) asm volatile("" : "+s"(epi_word));
 #define has_acc (EPI && (epi_word & 1) != 0)
 #define auto_reset (EPI && (epi_word & 2) != 0)
     const bool rand_act = EPI && MODE == kRollout && (epi_flags & 4) != 0;
@@ -583,14 +583,16 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     g_u8 *o_done = (g_u8 *)(a.done + (SYM ? env0 : 0));
     g_i32 *o_t = (g_i32 *)(a.t + (SYM ? env0 : 0));
     g_u32x4 *o_acc = (g_u32x4 *)(a.acc + 8 * (size_t)(SYM ? env0 : 0));
-    // (kSym64 only for now: the workgroup-per-env kernels of the episode layer sit at 85 scalar registers without them)
-    if (SYM && MODE != kObserve)
+    // (kSym64 only for now: the workgroup-per-env kernels of the episode layer sit at 85 scalar registers without them;
+    // not the fused rollout with the episode layer either, which is at its register limits as it is)
+    constexpr bool PIN = SYM && !(MODE == kRollout && EPI);
+    if (PIN && MODE != kObserve)
         asm volatile("" : "+s"(o_reward), "+s"(o_true), "+s"(o_pos), "+s"(o_vel), "+s"(o_gz), "+s"(o_gn),
                           "+s"(k_q), "+s"(k_b), "+s"(k_ghost), "+s"(k_done_radius), "+s"(k_last_t));
-    else if (SYM)
+    else if (PIN)
         asm volatile("" : "+s"(o_reward), "+s"(o_true), "+s"(o_gz), "+s"(o_gn), "+s"(k_q), "+s"(k_b), "+s"(k_ghost));
-    if (SYM && MODE != kObserve) asm volatile("" : "+s"(o_ncoll), "+s"(o_done), "+s"(o_t));
-    if (SYM && EPI) asm volatile("" : "+s"(o_acc));
+    if (PIN && MODE != kObserve) asm volatile("" : "+s"(o_ncoll), "+s"(o_done), "+s"(o_t));
+    if (PIN && EPI) asm volatile("" : "+s"(o_acc));
 
     // @phase lds_setup
     // ---- LDS carve-up (all region sizes multiples of 16 bytes); wave-local geometries give every wave
@@ -625,7 +627,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 
     // (Delta_j, l_j) of a partner: kernel-argument scalars when all agents share them -- except in the fused
     // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
-    const bool uni_args = MODE != kRollout && uniform;
+    const bool uni_args = SYM || (MODE != kRollout && uniform);   // (kSym64: always uniform; scalar registers cost it nothing)
     if (WL) {
         if (!SYM && (int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;   // kSym64 keeps these verdicts in scalar registers
         if (!uni_args && (int)lane < N)
@@ -680,15 +682,20 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     list0.init(dii, agent);
     float sum0_all = 0.f, sum0_msk = 0.f;
     int ncoll0 = 0;
-    if (SYM) {
+    if (PIN) {
         asm volatile("" : "+v"(thr), "+v"(log2_dhat), "+v"(dii), "+v"(in_range0), "+v"(zrow_a), "+v"(nrow_a), "+v"(copy_a),
                           "+v"(self_bit));
-        if (MODE != kRollout) {
-            list0.pin();
-            asm volatile("" : "+v"(sum0_all), "+v"(sum0_msk), "+v"(ncoll0));
-        }
+        list0.pin();                                         // (fused rollout: once per launch instead of twice per step)
+        asm volatile("" : "+v"(sum0_all), "+v"(sum0_msk), "+v"(ncoll0));
         __builtin_amdgcn_sched_barrier(0);                   // nothing of the above sinks behind the first use of the state
     }
+
+    // per-step outputs of the fused rollout: running bases, advanced by one step's worth at the end of every step (two
+    // scalar adds each; formed as base + step * stride they cost a 64-bit multiply chain and a 64-bit vector add per store)
+    g_f32 *p_reward = o_reward, *p_true = o_true;
+    g_u32 *p_gz = o_gz, *p_gn = o_gn;
+    g_i32 *p_ncoll = o_ncoll;
+    g_u8 *p_done = o_done;
 
     // @phase integrate
     for (int step = 0; step < nsteps; ++step) {
@@ -1041,8 +1048,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             const float to_goal = k_q * err2;
             r_out = -nan_to_num_f32(fmaf(k_b, s_msk, to_goal));
             tr_out = -nan_to_num_f32(fmaf(k_b, s_all, to_goal));
-            if (w_reward) st_g(o_reward + so + lane, r_out);
-            if (w_true) st_g(o_true + so + lane, tr_out);
+            if (w_reward) st_g(p_reward + lane, r_out);
+            if (w_true) st_g(p_true + lane, tr_out);
 #if defined(DRONESIM_ABL_NOSUM)
             if (false) {
 #else
@@ -1162,7 +1169,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #else
         if (staged && nval > 0) {
 #endif
-            g_u32 *gzg = o_gz + so * kZRow, *gng = o_gn + so * kNRow;
+            g_u32 *gzg = p_gz, *gng = p_gn;
             unsigned *gz = (unsigned *)gzg, *gn = (unsigned *)gng;              // (generic views for the ragged copy)
             // wave-uniform row bases: pinned in SGPRs so that the stores below address as scalar base + 32-bit lane
             // offset (the compiler otherwise builds 64-bit per-lane addresses: three v_lshl_add_u64 and two v_mad_i64_i32)
@@ -1219,9 +1226,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                                   l0 ? w1.x : accw.z, l0 ? w1.y : accw.w);
             }
             if (lane == 0) {
-                const size_t eo = (MODE == kRollout) ? (size_t)step * a.E : 0;
-                if (w_ncoll) o_ncoll[eo] = coll_s;
-                if (MODE != kObserve) o_done[eo] = (uint8_t)fin;
+                if (w_ncoll) *p_ncoll = coll_s;
+                if (MODE != kObserve) *p_done = (uint8_t)fin;
             }
         } else
         if (valid && (agent == 0 || (has_acc && agent == 1))) {
@@ -1455,7 +1461,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
             }
         }
-        if (MODE == kRollout) group_sync<WL>();               // staging / sred reuse by the next step
+        if (MODE == kRollout) {
+            group_sync<WL>();                                 // staging / sred reuse by the next step
+            p_reward += step_agents; p_true += step_agents;
+            p_gz += step_agents * kZRow; p_gn += step_agents * kNRow;
+            p_ncoll += a.E; p_done += a.E;
+        }
     }
     if (SYM) {                                                // scalar bases + lane offsets
         if (MODE != kObserve && lane == 0) *o_t = tcur;
