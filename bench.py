@@ -146,7 +146,7 @@ def step_kernel_ms(torch, env, pool, n_samp, reps=10):
     return float(np.median(samples))
 
 
-def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25):
+def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precision="f32"):
     """One of the other BASELINE configs, timed in this process after the graded region: the same step path
     (episode layer, hipGraph replay), single GPU.  Returns the block appended under `other_workloads`."""
     from scalable_collision_avoidance_rl_amd import drones, max_time_steps
@@ -156,7 +156,7 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25):
     T_ep = max_time_steps
     g = torch.Generator(device=dev).manual_seed(99)
     pool = torch.rand(T_ep, E, N, 2, device=dev, generator=g) * 2 - 1
-    policy = make_policy(torch, policy_kind, "f32", N, dev) if policy_kind else None
+    policy = make_policy(torch, policy_kind, precision, N, dev) if policy_kind else None
 
     def one_step(s):
         if policy is None:
@@ -185,7 +185,8 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25):
     steps = L * repeats
     kern_ms = step_kernel_ms(torch, env, pool, 5 * T_ep, reps=5)
     byt = algorithmic_bytes(N, E, True)
-    out = {"workload": label + (f" + float32 {policy_kind} policy in the loop (BASELINE configs[4], one shard)" if policy else ""),
+    arith = {"f32": "exact float32 (v_mfma_f32_32x32x2_f32)", "bf16x3": "float32-accurate three-part bf16 split (6 x v_mfma_f32_32x32x16_bf16 per 16 k)"}.get(precision, precision)
+    out = {"workload": label + (f" + {policy_kind} policy in the loop, {arith} (BASELINE configs[4], one shard)" if policy else ""),
            "value": N * E * steps / el, "unit": "agent-steps/s", "ms_per_step": el / steps * 1e3, "timed_steps": steps,
            "timed_seconds": el, "step_kernel_ms": kern_ms,
            "roofline": {"bound": "hbm", "achieved": byt / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -202,9 +203,16 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25):
         pol_ms = e0.elapsed_time(e1) / 20
         flops = 2.0 * E * N * (policy.d_in * policy.h1 + policy.h1 * policy.h2 + policy.h2 * policy.nout)
         out["policy_kernel_ms"] = pol_ms
-        out["policy_roofline"] = {"bound": "mfma", "achieved": flops / (pol_ms * 1e-3) / 1e12, "peak": 157.3,
-                                  "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / 157.3,
-                                  "kernel": "mlp3_kernel (v_mfma_f32_32x32x2_f32, exact float32)"}
+        if precision == "f32":
+            out["policy_roofline"] = {"bound": "mfma", "achieved": flops / (pol_ms * 1e-3) / 1e12, "peak": 157.3,
+                                      "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / 157.3,
+                                      "kernel": "mlp3_kernel (v_mfma_f32_32x32x2_f32, exact float32)"}
+        else:                                          # six bf16 products per float32-equivalent product on the 2.5 PFLOP/s pipe
+            mf = 6.0 * flops
+            out["policy_roofline"] = {"bound": "mfma", "achieved": mf / (pol_ms * 1e-3) / 1e12, "peak": 2500.0,
+                                      "unit": "TFLOP/s", "frac": mf / (pol_ms * 1e-3) / 1e12 / 2500.0,
+                                      "float32_equivalent_tflops": flops / (pol_ms * 1e-3) / 1e12,
+                                      "kernel": "mlp3_split_kernel<SchemeBf16x3> (bf16 matrix flops actually issued: 6 per float32 product)"}
     del graph, env, pool
     torch.cuda.empty_cache()
     return out
@@ -548,9 +556,10 @@ def main():
             del pool
             torch.cuda.empty_cache()
             other = {}
-            for key, wl, pk in (("c2", "c2", None), ("c5_env", "c5", None), ("c5_gaussian_f32", "c5", "gaussian")):
+            for key, wl, pk, pr in (("c2", "c2", None, "f32"), ("c5_env", "c5", None, "f32"),
+                                    ("c5_gaussian_f32", "c5", "gaussian", "f32"), ("c5_gaussian_bf16x3", "c5", "gaussian", "bf16x3")):
                 try:
-                    other[key] = side_workload(torch, dev, wl, pk)
+                    other[key] = side_workload(torch, dev, wl, pk, precision=pr)
                 except Exception as ex:                 # a side measurement must never cost the headline line
                     other[key] = {"error": f"{type(ex).__name__}: {ex}"}
             out["other_workloads"] = other

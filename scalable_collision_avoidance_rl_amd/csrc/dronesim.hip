@@ -497,7 +497,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // (kSym64: the word is made opaque so that every test is one s_bitcmp on it; as boolean values the compiler keeps
     // them as 64-bit lane masks and spends a v_cndmask / v_cmp pair on each negation)
     int epi_word = epi_flags;
+#if !defined(DRONESIM_TRACE)
     if (SYM && EPI && MODE != kRollout) asm volatile("" : "+s"(epi_word));
+#endif
 #define has_acc (EPI && (epi_word & 1) != 0)
 #define auto_reset (EPI && (epi_word & 2) != 0)
     const bool rand_act = EPI && MODE == kRollout && (epi_flags & 4) != 0;
@@ -585,7 +587,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     g_u32x4 *o_acc = (g_u32x4 *)(a.acc + 8 * (size_t)(SYM ? env0 : 0));
     // (kSym64 only for now: the workgroup-per-env kernels of the episode layer sit at 85 scalar registers without them;
     // not the fused rollout with the episode layer either, which is at its register limits as it is)
+#if defined(DRONESIM_TRACE)                                    // (the trace build's stamps make hipcc lose the uniformity)
+    constexpr bool PIN = false;
+#else
     constexpr bool PIN = SYM && !(MODE == kRollout && EPI);
+#endif
     if (PIN && MODE != kObserve)
         asm volatile("" : "+s"(o_reward), "+s"(o_true), "+s"(o_pos), "+s"(o_vel), "+s"(o_gz), "+s"(o_gn),
                           "+s"(k_q), "+s"(k_b), "+s"(k_ghost), "+s"(k_done_radius), "+s"(k_last_t));

@@ -343,6 +343,35 @@ def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch, prec):
     assert abs((eps ** 4).mean() - 3.0) < 0.08                                    # Gaussian, not just unit variance
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_c5_gaussian_policy_stress_weights_hold_the_bar(torch, prec):
+    """The precisions the C5 line is quoted with (bench.py `other_workloads.c5_gaussian_*`) hold the 1e-5 bar on the
+    C5 shard's OWN observation (|z| up to ~243 on the 256 grid) at the builder's stress weights -- the case of
+    tools/policy_accuracy.py / profiles/r2_policy_accuracy.log: full 400 x 4 output matrix at 2-3x the reference's
+    initialisation (utils.py:64-108 initialises U(+-1/sqrt(in))), where the two-part float16 split (f16x2) is at 2.0x
+    the bar and therefore NOT what C5 is quoted with."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    N, E, G = 256, 512, 256.0
+    env = make_env(N, G, 2, 2, np.ones(N) * 2.5, E, seed=1)
+    z = env.z
+    assert float(z.abs().max()) > 200.0
+    g = torch.Generator().manual_seed(1)
+    r = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1)
+    sc = 0.08
+    w = (r(N, 6, 400) * sc, r(N, 400) * sc, r(N, 400, 400) * sc, r(N, 400) * sc, r(N, 400, 4) * sc * 2, r(N, 4) * sc)
+    zd = z.double().cpu().reshape(E, N, 6)
+    W = [t.double() for t in w]
+    h = torch.relu(torch.einsum("end,ndh->enh", zd, W[0]) + W[1])
+    h = torch.relu(torch.einsum("enh,nhk->enk", h, W[2]) + W[3])
+    y = torch.einsum("enk,nko->eno", h, W[4]) + W[5]
+    ref = torch.cat([torch.tanh(y[..., :2]), torch.sigmoid(y[..., 2:])], -1).numpy()
+    assert float(h.abs().max()) > 20.0                                    # hidden activations well beyond the init regime
+    pol = BatchedMLP(*w, out_kind=2, sample_kind=0, precision=prec)
+    out = host(pol.forward(z)).astype(np.float64)
+    err = np.abs(out - ref) / (H.ATOL + H.RTOL * np.abs(ref))
+    assert err.max() <= 1.0, f"{prec}: worst error {err.max():.3f} x the 1e-5 bar"
+
+
 def test_observe_matches_oracle_and_mask(torch):
     N, G, E = 64, 28.0, 300
     rng = np.random.default_rng(5)
