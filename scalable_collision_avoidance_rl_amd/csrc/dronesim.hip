@@ -66,6 +66,7 @@ constexpr int kBucketMinN = 40;     // packed envs smaller than this scan all pa
 #define DRONESIM_SKIN 0.4f          // fused rollout: slack of the register-resident candidate list, in units of the reach
 #endif
 constexpr int kBucketMax = 10;      // candidates per agent beyond which the all-pairs scan is cheaper
+constexpr int kFarAllMaxN = 8;      // FAR variant: envs this small send every pair through pass 2 (no filter, no far tail)
 constexpr float kLn2 = 0.693147180559945309f;
 
 enum Mode { kStep = 0, kObserve = 1, kRollout = 2 };
@@ -91,7 +92,8 @@ struct KArgs {
     uint8_t *done;
     const uint8_t *mask;
     float skin;                     // rollout, kSym64: slack radius of the register-resident candidate list
-    int bucket;                     // packed geometry: use the bucket far filter (N >= 24)
+    int bucket;                     // packed geometry: use the bucket far filter (N >= kBucketMinN)
+    int far_inm;                    // FAR: some clipped distance can pass a Delta mask (Delta_j >= dhat_i possible, e.g. deltas=None)
     int uniform;                    // all agents share d_hat, Delta and radius (host-known): constants come
     float dhat_u, delta_u, radius_u;   //   from the kernel arguments, no per-agent table is read
     // episode bookkeeping / in-kernel reset / in-kernel random actions (DroneEpisodeCtl; all off when zero)
@@ -625,7 +627,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // 40 % of the kernel's LDS cycles; at 8 bytes per cell the 23 cells of C3 are conflict-free.)
     unsigned long long *sbx = sbt_all + (size_t)wave * (2 * kCells), *sby = sbx + kCells;
     const int W = BLOCKGEO ? nwaves : 1;
-    const bool use_bucket = !FAR && !SYM && (BLOCKGEO || a.bucket != 0);                   // launch-uniform
+    const bool use_bucket = !SYM && (BLOCKGEO || a.bucket != 0);                           // launch-uniform
     unsigned long long *sbt = sbt_all + (size_t)slot * (2 * kCells) * W;                   // this lane's env
     // tail (episode bookkeeping): per-wave partial reward sums [nwaves][2], then the sampling tables of the in-kernel
     // reset, [epb][samp_tbl] x (node, owner)
@@ -696,6 +698,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         __builtin_amdgcn_sched_barrier(0);                   // nothing of the above sinks behind the first use of the state
     }
 
+    // FAR with Delta_j >= dhat_i possible: how many partners j != i a distance clipped to dhat_i leaves inside their
+    // Delta mask (position-independent; the far tail of every step uses it).  Non-uniform envs count it in the first
+    // step, once the (Delta_j, l_j) table in LDS is visible.
+    int far_total = (FAR && a.far_inm && uniform && a.dhat_u <= a.delta_u) ? N - 1 : 0;
+
     // per-step outputs of the fused rollout: running bases, advanced by one step's worth at the end of every step (two
     // scalar adds each; formed as base + step * stride they cost a 64-bit multiply chain and a 64-bit vector add per store)
     g_f32 *p_reward = o_reward, *p_true = o_true;
@@ -734,10 +741,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             spos_env[agent] = make_float2(xi, yi);
             if (!use_bucket && !SYM) {                        // relative partner windows (dup index agent + r);
                 spos_env[agent + N] = make_float2(xi, yi);    // kSym64 writes them only when its fallback runs
-                if (!FAR) {
-                    spos_env[stride + agent + 1] = make_float2(xi, yi);
-                    spos_env[stride + agent + N + 1] = make_float2(xi, yi);
-                }
+                spos_env[stride + agent + 1] = make_float2(xi, yi);
+                spos_env[stride + agent + N + 1] = make_float2(xi, yi);
             }
         }
         // @phase filter_generic
@@ -752,6 +757,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         TRACE_MARK(1);
         group_sync<WL>();
         TRACE_MARK(2);
+        if (FAR && step == 0 && a.far_inm && !uniform && valid) {
+#pragma nounroll
+            for (int j = 0; j < N; ++j) far_total += (j != agent && dhat <= sconst[j].x) ? 1 : 0;
+        }
         if (use_bucket) {
             if (valid) {
                 atomicOr(&sbt[(agent >> 6) * kCells + bcx], 1ull << (agent & 63));           // [axis][word][cell]:
@@ -767,6 +776,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         int ncoll = ncoll0;
         NbrList<K, ASC> list = list0;                         // holds the self entry
         int in_range = in_range0;                             // :346, minus itself
+        // FAR: the partners pass 2 has visited (absolute agent index, one bit each), and how many of them a distance
+        // clipped to dhat_i would leave inside their Delta mask -- what the dense far tail below subtracts
+        unsigned long long vis[FAR ? WMAX : 1];
+#pragma unroll
+        for (int w = 0; w < (FAR ? WMAX : 1); ++w) vis[w] = 0ull;
+        int vis_inm = 0;
 
         // @phase pass2_visit
         // pass 2 body: the pair (this agent, partner at index jdup of the doubled position array)
@@ -784,6 +799,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             s_msk += pt.inm ? pt.lg : 0.0f;                                   // :282
             ncoll += pt.coll ? 1 : 0;                                         // :284
             in_range += pt.inm ? 1 : 0;
+            if (FAR) vis_inm += (dhat <= cj.x) ? 1 : 0;
             list.template insert<decltype(defer)::value>(pt.d, j, dii);      // :338
         };
 
@@ -868,6 +884,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     }
                 }
             };
+            if (FAR) {
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) vis[w] = (w < W) ? pool[w] : 0ull;
+            }
             if (ASC) {
                 if (uni_args) walk(Defer{}, UniArgs{}); else walk(Defer{}, UniRuntime{});
                 if (__builtin_expect(list_degenerate(list), 0)) {
@@ -890,7 +910,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
 #if defined(DRONESIM_ABLATE_PASS1)
                 if (true) { near = (xi == 123.456f) ? 1ull : 0ull; } else
 #endif
-                if (FAR) {
+                if (FAR && N <= kFarAllMaxN) {
+                    // a handful of agents: every partner goes through pass 2 (the filter and the far tail cost more than
+                    // the few far pairs they would save: N = 5 x 1024 envs 4.0 us this way, 4.66 us filtered)
                     near = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
                 } else if (SYM) {
                     // bit u < 32: partner i+1+u ("forward");  bit 32+u: partner i-1-u ("backward", u < 31)
@@ -1031,14 +1053,56 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                             visit(u, NoDefer{}, UniRuntime{});
                         }
                     }
-                } else
+                } else {
+                if (FAR) {
+                    // bit u of `near` is partner (agent + r0 + u) mod N: rotate into absolute agent indices.  This scan
+                    // runs for packed envs of N < kBucketMinN agents only: one chunk (r0 = 1), all shifts below 64.
+                    const int sh = agent + r0, back = N - sh;                         // 1 <= sh <= N - 1 + 1
+                    const unsigned long long lo = sh < 64 ? near << sh : 0ull;
+                    const unsigned long long hi = back > 0 ? near >> back : near;
+                    vis[0] |= (lo | hi) & ((N < 64) ? ((1ull << N) - 1ull) : ~0ull);
+                }
                 while (near) {
                     const int u = __builtin_ctzll(near);
                     near &= near - 1ull;
                     visit(agent + r0 + u, NoDefer{}, UniRuntime{});
                 }
+                }
             }
         }
+        // @phase far_tail
+        if (FAR && valid && !(!use_bucket && N <= kFarAllMaxN)) {
+            // ---- Far partners (d^2 >= reach^2: never visited above).  Their clipped distance is dhat_i EXACTLY (:318), so
+            // the log term is 0, they are no collision (dhat > 0), and they are inside the column's Delta mask iff
+            // dhat_i <= Delta_j -- none of which depends on where the partner is.  The row sums and the collision count are
+            // therefore complete as they stand; the Delta count gets (count over all j != i, position-independent) minus
+            // (the visited partners' share of it); and since all far partners tie at dhat_i, the stable argsort (:338)
+            // lists them by index: the K lowest-index unvisited agents are offered to the list (keyed insertion: a
+            // visited partner that was clipped to exactly dhat_i ties with them and sorts by index like them).
+            // Round 2 sent every ordered pair of such envs (c = 5, or deltas=None) through sqrt / log / the insertion.
+            if (a.far_inm) in_range += far_total - vis_inm;
+            unsigned long long fr[WMAX];
+#pragma unroll
+            for (int w = 0; w < WMAX; ++w) {
+                const int nw = N - 64 * w;                                        // agents in this word
+                const unsigned long long live = nw >= 64 ? ~0ull : (nw > 0 ? (1ull << nw) - 1ull : 0ull);
+                fr[w] = ~vis[w] & live;
+                if (w == (agent >> 6)) fr[w] &= ~(1ull << (agent & 63));
+            }
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                int j = -1;
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) {
+                    if (j < 0 && fr[w] != 0ull) {
+                        j = 64 * w + __builtin_ctzll(fr[w]);
+                        fr[w] &= fr[w] - 1ull;
+                    }
+                }
+                if (j >= 0) list.template insert<false>(dhat, j, dii);
+            }
+        }
+
         // @phase epilogue_rewards_z
         float r_out = 0.0f, tr_out = 0.0f;                    // this lane's rewards (episode bookkeeping)
         float r_env = 0.0f, tr_env = 0.0f;                    // their sums over the env, valid in its agent-0 lane
@@ -2151,7 +2215,8 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     // far agents matter when a z row carries (v, l) of a tie-ordered agent (c = 5) or
     // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)
     const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
-    a.bucket = (g.P > 0 && p->N >= kBucketMinN && !far) ? 1 : 0;
+    a.bucket = (g.P > 0 && p->N >= kBucketMinN) ? 1 : 0;
+    a.far_inm = !(p->delta_max < p->d_hat_min) ? 1 : 0;
 #if !defined(DRONESIM_NO_SYM64)
     if (p->N == 64 && !far && a.uniform && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
         g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane; uniform (d_hat, Delta, radius) only

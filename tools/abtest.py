@@ -5,6 +5,7 @@
     python tools/abtest.py <rounds> <cases> lib_a.so lib_b.so ...
     cases: comma list of  c3 (plain step) | c3e (step, episode layer + auto-reset: the graded kernel) | c3r (fused rollout)
            | c3rr (fused rollout, actions drawn in the kernel, episode layer) | c5 | c5e | c5r | c2 | NxE:G:delta[e|r]
+           | c3f / c5f / NxE:G:deltaf (the reference's DEFAULT construction: deltas=None, simplify_zstate=False -> FAR variant)
 
 Every (round, library) runs in its own process (the library is chosen at import time through DRONESIM_LIB)."""
 import json
@@ -26,7 +27,7 @@ def one(cases):
     for case in cases:
         mode = "plain"
         spec = case
-        for suffix, m in (("rr", "rollout_random"), ("r", "rollout"), ("e", "epi")):
+        for suffix, m in (("rr", "rollout_random"), ("r", "rollout"), ("e", "epi"), ("f", "far")):
             if spec.endswith(suffix) and (spec[:-len(suffix)] in PRESETS or ":" in spec):
                 spec, mode = spec[:-len(suffix)], m
                 break
@@ -36,11 +37,14 @@ def one(cases):
             ne, G, delta = spec.split(":")
             N, E = (int(x) for x in ne.split("x")); G, delta = float(G), float(delta)
         kw = dict(auto_reset=True) if mode in ("epi", "rollout_random") else {}
-        env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1, **kw)
+        if mode == "far":        # the reference's DEFAULT construction: deltas=None (Delta = d_hat), simplify_zstate=False (c = 5)
+            env = drones(N, 0, [G, G], "O", n_envs=E, batched=True, seed=1)
+        else:
+            env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1, **kw)
         g = torch.Generator(device="cuda").manual_seed(0)
         T = 200
         ts = []
-        if mode in ("plain", "epi"):
+        if mode in ("plain", "epi", "far"):
             pool = torch.rand(T, E, N, 2, device="cuda", generator=g) * 2 - 1
             for s in range(10):
                 env.step(pool[s])
