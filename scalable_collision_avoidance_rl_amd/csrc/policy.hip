@@ -204,6 +204,14 @@ __device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, 
     if (Kmain > 0) {
         Frag cur, nxt;
         load_frag<false>(cur, Arow, Bcol, ldb, kk, K);
+        // The first stage's operands are waited for HERE, once, ahead of the loop.  Left pending into the loop, they make
+        // hipcc place counted waits (vmcnt(7) ... vmcnt(0)) in front of the eight MFMAs of the loop body -- needed on
+        // the first trip, where the MFMAs' operands are those loads, but the same instructions then also wait on every
+        // later trip, where the only loads in flight are the NEXT stage's: the prefetch distance collapsed from a full
+        // stage (512 cycles of MFMAs) to the position inside the stage, and every stage stalled on the L2 latency
+        // (round 2: 0.46 of the matrix peak).  With nothing pending at the loop's entry the only wait left is the one
+        // in front of the `cur = nxt` copies, a whole stage after the loads were issued.
+        __builtin_amdgcn_s_waitcnt(0x0070);                // vmcnt(0) lgkmcnt(0)
         for (int k0 = 0; k0 < Kmain; k0 += 2 * kU) {
             const bool more = k0 + 2 * kU < Kmain;         // wave-uniform
             if (more) load_frag<false>(nxt, Arow, Bcol, ldb, k0 + 2 * kU + kk, K);
@@ -230,9 +238,11 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 3, rh = wave >> 2;
     int agent, row_block;
     xcd_work_item((a.E + kRows - 1) / kRows, agent, row_block);
+    // (rotating which wave owns the chunks 0, 4, 8, ... -- one more chunk than the others at h = 400 -- with the row block,
+    // so that the heavy waves of the two workgroups on a CU sit on different SIMDs, was measured in round 3: +-1 %)
+    const int cw = wave & 3, rh = wave >> 2;
     const int e0 = row_block * kRows;
     const int ldx = a.d_in + 1, ld1 = a.h1 + 1;
     float *sx = reinterpret_cast<float *>(smem);                 // [rows][d_in+1]
