@@ -1030,44 +1030,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     // general insertion, out of line
                     const unsigned long long near0 = near;
                     if (uni_args) {
-#if !defined(DRONESIM_NO_PAIR_ILP)
-                        // Two partners per trip, their pair arithmetic interleaved (independent chains of ~25 dependent
-                        // instructions each): the launch ends with the few waves whose worst lane has 4-5 partners
-                        // (`profiles/r3_trace_phases_ablated.log`), and their walk is a serial chain of ~570 cycles per
-                        // trip.  A lane without a second partner repeats its first one with the verdicts masked: adding
-                        // +0.0 to the (non-negative) sums and offering +inf to the list are exact no-ops, so the results
-                        // are bit-identical to the one-partner walk the other paths use.
-                        while (near) {
-                            const int u0 = __builtin_ctzll(near);
-                            near &= near - 1ull;
-                            const bool has1 = near != 0ull;
-                            const int u1 = has1 ? __builtin_ctzll(near) : u0;
-                            near &= near - 1ull;                          // (0 stays 0)
-                            const float2 p0 = spos_env[u0], p1 = spos_env[u1];
-                            const float dx0 = xi - p0.x, dy0 = yi - p0.y, dx1 = xi - p1.x, dy1 = yi - p1.y;
-                            const float q0 = fmaf(dy0, dy0, dx0 * dx0), q1 = fmaf(dy1, dy1, dx1 * dx1);
-                            const bool on0 = !CACHED || q0 < thr;          // (fused rollout: listed but currently far)
-                            const bool on1 = has1 && (!CACHED || q1 < thr);
-                            const PairTerms<float> t0 = pair_terms<float>(q0, li, a.radius_u, dhat, log2_dhat, a.delta_u);
-                            const PairTerms<float> t1 = pair_terms<float>(q1, li, a.radius_u, dhat, log2_dhat, a.delta_u);
-                            s_all += on0 ? t0.lg : 0.0f;
-                            s_msk += (on0 && t0.inm) ? t0.lg : 0.0f;
-                            ncoll += (on0 && t0.coll) ? 1 : 0;
-                            in_range += (on0 && t0.inm) ? 1 : 0;
-                            list.template insert<true>(on0 ? t0.d : __builtin_inff(), u0, dii);
-                            s_all += on1 ? t1.lg : 0.0f;
-                            s_msk += (on1 && t1.inm) ? t1.lg : 0.0f;
-                            ncoll += (on1 && t1.coll) ? 1 : 0;
-                            in_range += (on1 && t1.inm) ? 1 : 0;
-                            list.template insert<true>(on1 ? t1.d : __builtin_inff(), u1, dii);
-                        }
-#else
                         while (near) {
                             const int u = __builtin_ctzll(near);
                             near &= near - 1ull;
                             visit(u, Defer{}, UniArgs{});
                         }
-#endif
                     } else {
                         while (near) {
                             const int u = __builtin_ctzll(near);
