@@ -322,23 +322,62 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
         for (int i = 0; i < kQ; ++i) b3v[i] = (tid & 3) + 4 * i < a.nout ? b3[(tid & 3) + 4 * i] : 0.0f;
     }
 
-    // ---- layers 2 + 3 fused over this wave's column chunks
+    // ---- layers 2 + 3 fused over this wave's column chunks.  The chunk count is rarely a multiple of four (13 at
+    // h = 400, 10 at h = 300, 7 at h = 200): dealt whole, one wave gets a chunk more than the others, runs 4 : 3 longer and
+    // the other three wait for it holding their slots (round 3 trace: 140k against 110-116k cycles per wave, the matrix
+    // pipe 54 % busy).  So only whole rounds of four chunks are dealt; every LEFTOVER chunk is split over the four waves
+    // by K (each wave a quarter of the h1 range), the partial tiles meet in LDS and one wave finishes the chunk.
     f32x16 y = {0};
     float *st = sst + wave * 32 * 33;
-    for (int c0 = cw * 32; c0 < a.h2; c0 += 128) {
+    const int nch = (a.h2 + 31) >> 5;
+    // ... when exactly ONE chunk is left over (13 chunks at h = 400: measured -5.5 % at the C5 shard, -4.3 % at C3); with two
+    // or three leftover chunks (h = 300, h = 200) the two barriers and the serial finish per chunk cost more than the
+    // balance gains (+1.5 % / +19 %), so those deal their chunks whole as before
+#if defined(POLICY_NO_KSPLIT)
+    const int nch_even = nch;
+#else
+    const int nch_even = (nch & 3) == 1 ? (nch & ~3) : nch;
+#endif
+    // ONE loop over both kinds of trips (one inlined copy of each GEMM: a second copy of the layer-2 loop took the kernel
+    // from 244 to 272 registers, i.e. from two workgroups per CU to one): first the whole rounds, then the leftover chunks
+    const int rounds = (nch_even + 3) >> 2;                      // (whole dealing: the last round may be ragged)
+    const int kq = (((a.h1 + 3) >> 2) + 1) & ~1;                 // a quarter of K, even
+    for (int it = 0; it < rounds + (nch - nch_even); ++it) {     // wave-uniform trip count (barriers inside)
+        const bool left = it >= rounds;                          // leftover chunk: this wave's K quarter of it
+        const int c0 = (left ? nch_even + (it - rounds) : cw + 4 * it) * 32;
+        if (!left && c0 >= nch_even * 32) continue;              // ragged last round of the whole dealing (no barrier in it)
+        const int kb = left ? min(cw * kq, a.h1) : 0, kn = left ? min(kq, a.h1 - kb) : a.h1;
         const bool ok = c0 + col < a.h2;
         const float bias = ok ? b2[c0 + col] : 0.0f;             // issued before the k-loop, needed after it
         f32x16 acc = {0};
-        tile_gemm(acc, sh1 + rh * 32 * ld1, ld1, w2 + c0, a.h2, a.h1, a.h2 - c0, lane);
+        if (kn > 0)
+            tile_gemm(acc, sh1 + rh * 32 * ld1 + kb, ld1, w2 + c0 + (size_t)kb * a.h2, a.h2, kn, a.h2 - c0, lane);
+        bool l3 = true;                                          // this wave feeds the chunk to layer 3
+        if (!left) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = ok ? fmaxf(acc[r] + bias, 0.0f) : 0.0f;
+            for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = ok ? fmaxf(acc[r] + bias, 0.0f) : 0.0f;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = acc[r];      // this wave's partial tile
+            __syncthreads();
+            l3 = cw == ((it - rounds) & 3);                      // one wave adds the four partials in a fixed order
+            if (l3) {
+                const float *p0 = sst + (rh * 4) * 32 * 33;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = cd_row(r, lane) * 33 + col;
+                    const float v = ((p0[o] + p0[32 * 33 + o]) + p0[2 * 32 * 33 + o]) + p0[3 * 32 * 33 + o];
+                    st[o] = ok ? fmaxf(v + bias, 0.0f) : 0.0f;
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int kc = min(32, a.h2 - c0);
-        tile_gemm(y, st, 33, w3 + (size_t)c0 * a.nout, a.nout, kc, a.nout, lane);
+        if (l3) tile_gemm(y, st, 33, w3 + (size_t)c0 * a.nout, a.nout, min(32, a.h2 - c0), a.nout, lane);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (left) __syncthreads();                               // the partial regions are free again
     }
     PT(4);
 #pragma unroll
