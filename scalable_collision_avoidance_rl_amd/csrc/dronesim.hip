@@ -94,6 +94,8 @@ struct KArgs {
     float skin;                     // rollout, kSym64: slack radius of the register-resident candidate list
     int bucket;                     // packed geometry: use the bucket far filter (N >= kBucketMinN)
     int far_inm;                    // FAR: some clipped distance can pass a Delta mask (Delta_j >= dhat_i possible, e.g. deltas=None)
+    int stage5;                     // c = 5: the 5 (k+1)-word z rows are staged through LDS too and the velocities of the env's
+    int lds_vel;                    //        agents sit in LDS at this byte offset (both sized by the host when they fit)
     int uniform;                    // all agents share d_hat, Delta and radius (host-known): constants come
     float dhat_u, delta_u, radius_u;   //   from the kernel arguments, no per-agent table is read
     // episode bookkeeping / in-kernel reset / in-kernel random actions (DroneEpisodeCtl; all off when zero)
@@ -614,12 +616,14 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     int *sred = reinterpret_cast<int *>(sconst_all + (size_t)nconst * (N + (N & 1)));      // [epb][2]
     const int nred = 2 * a.epb + ((2 * a.epb) & 3 ? 4 - ((2 * a.epb) & 3) : 0);
     unsigned *sstage = reinterpret_cast<unsigned *>(sred + nred);
-    unsigned *stage_z = sstage + (size_t)wave * kWave * (kZRow + kNRow);                   // [64][kZRow]
-    unsigned *stage_n = stage_z + kWave * kZRow;                                           // [64][kNRow]
+    // c = 2: [64][kZRow] z words + [64][kNRow] Ni words per wave; FAR with staged c = 5 rows: 5 (K+1) z words per lane
+    const int zrow_w = (FAR && a.stage5) ? 5 * (K + 1) : kZRow;
+    unsigned *stage_z = sstage + (size_t)wave * kWave * (zrow_w + kNRow);
+    unsigned *stage_n = stage_z + kWave * zrow_w;
     float2 *sconst = sconst_all + (WL ? (size_t)wave * (N + (N & 1)) : 0);
     // bucket filter tables.  kSym64: per wave, cell -> lane mask, entries -1..64 of (x mask, y mask).
     // Other geometries: per env slot, [axis][W words of 64 agents][64 cells].
-    unsigned long long *sbt_all = reinterpret_cast<unsigned long long *>(sstage + (size_t)nwaves * kWave * (kZRow + kNRow));
+    unsigned long long *sbt_all = reinterpret_cast<unsigned long long *>(sstage + (size_t)nwaves * kWave * (zrow_w + kNRow));
     // kSym64: [x | y][64 cells] masks of 8 bytes per wave.  Agents live in cells 1..62 (coordinates beyond clamp to the
     // end cells, which only adds candidates), so cells 0 and 63 stay empty: every lane zeroes its own entry of either
     // table and reads cells c-1, c, c+1 without a guard row or an edge test.  (Round 2 kept (x, y) pairs at a 16-byte
@@ -659,7 +663,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // c = 5 rows carry (v, l) of tie-ordered agents, which forces the FAR variant on the host: every other
     // instantiation knows c = 2 at compile time (no dead c = 5 code, and no conservative s_waitcnt for its loads)
     const int zc = FAR ? a.c : 2;
-    const bool staged = zc == 2 && !masked;                  // z / Ni leave through LDS as full lines
+    const bool staged = (zc == 2 || (FAR && a.stage5)) && !masked;   // z / Ni leave through LDS as full lines
+    // FAR, c = 5: (vx, vy) of the env's agents in LDS (the rows of the k nearest carry them, :367 / :385)
+    // (addressed as integer LDS offsets, see the staging addresses below)
+    const unsigned svel_a = lds_addr(smem) + (unsigned)a.lds_vel + (unsigned)slot * (unsigned)N * 8u;
 
     // ---- candidate list (fused rollout of kSym64 only): the far filter is run with radius reach + skin and
     // its verdicts are kept in registers until some agent of the env has moved more than skin/2 from where
@@ -677,8 +684,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     int in_range0 = ((dii <= delta_i) ? 1 : 0) - 1;
     // this lane's slots of the wave's staging area (c = 2 rows leave through LDS as full lines): row of 2 (K+1) words of
     // z, row of K+1 words of Ni, and the 16 bytes per lane and round of the copy-out
-    unsigned zrow_a = lds_addr(stage_z) + lane * (4 * kZRow), nrow_a = lds_addr(stage_n) + lane * (4 * kNRow);
-    unsigned copy_a = lds_addr(stage_z) + lane * 16;
+    // (as offsets from the dynamic-LDS base: casting the derived generic pointers themselves makes hipcc emit an aperture
+    // null test that it then fails to select -- "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
+    const unsigned lds0 = lds_addr(smem);
+    const unsigned stage_z_a = lds0 + (unsigned)(reinterpret_cast<const char *>(stage_z) - smem);
+    unsigned zrow_a = stage_z_a + lane * (4 * kZRow);
+    unsigned nrow_a = lds0 + (unsigned)(reinterpret_cast<const char *>(stage_n) - smem) + lane * (4 * kNRow);
+    unsigned copy_a = stage_z_a + lane * 16;
     // formed in the shadow of the state loads, like the scalar side above
     unsigned long long self_bit = 1ull << lane;              // this lane's bit in the cell masks of the bucket filter
     // partners reach pass 2 in ascending agent order on every path of these geometries (bucket / symmetric filter)
@@ -739,6 +751,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 vxi = u.x; vyi = u.y;                         // drone_env.py:238
             }
             spos_env[agent] = make_float2(xi, yi);
+            if (FAR && a.stage5) { f32x2 v; v.x = vxi; v.y = vyi; *(lds_f32x2 *)(svel_a + 8u * (unsigned)agent) = v; }
             if (!use_bucket && !SYM) {                        // relative partner windows (dup index agent + r);
                 spos_env[agent + N] = make_float2(xi, yi);    // kSym64 writes them only when its fallback runs
                 spos_env[stride + agent + 1] = make_float2(xi, yi);
@@ -1152,7 +1165,34 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 zry[kth] = real ? pnb[kth].y - yi : ghy;
                 nbv[kth] = real ? (int)j : -1;
             }
-            if (!staged) {                                                    // c = 5 rows / masked observe
+            // c = 5 rows also carry (vx, vy, l) of the row's agent: the agent itself (:355), the listed neighbour or the
+            // tie-ordered agent behind a ghost row (:367 / :385), NaN where the list has no agent at all
+            float zvx[FAR ? K + 1 : 1], zvy[FAR ? K + 1 : 1], zvl[FAR ? K + 1 : 1];
+            if (FAR && zc == 5) {
+                zvx[0] = vxi; zvy[0] = vyi; zvl[0] = li;
+#pragma unroll
+                for (int kth = 1; kth <= K; ++kth) {
+                    const unsigned j = list.index(kth);
+                    float2 vj = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+                    float lj = __builtin_nanf("");
+                    if (have[kth]) {
+                        if (a.stage5) {
+                            const f32x2 v = *(const lds_f32x2 *)(svel_a + 8u * j);    // (written next to the positions, same sync)
+                            vj = make_float2(v.x, v.y);
+                        } else if (rand_act) {                                // counter-based stream: any lane can
+                            uint32_t o[4];                                    // restate any agent's action
+                            philox4x32_10(j, gid, (uint32_t)(tcur >> 1), epi, a.key0 ^ kRandActKey, a.key1, o);
+                            vj = (tcur & 1) ? make_float2(unit_action(o[2]), unit_action(o[3]))
+                                            : make_float2(unit_action(o[0]), unit_action(o[1]));
+                        } else {
+                            vj = reinterpret_cast<const float2 *>(velsrc)[(size_t)env * N + j];
+                        }
+                        lj = uni_args ? a.radius_u : sconst[j].y;
+                    }
+                    zvx[kth] = vj.x; zvy[kth] = vj.y; zvl[kth] = lj;
+                }
+            }
+            if (!staged) {                                                    // masked observe / c = 5 rows that do not fit LDS
                 const int c = zc;
                 float *zr = a.z + (so + wga0 + lane) * (size_t)((K + 1) * c);
                 int *nb = a.nbr_idx + (so + wga0 + lane) * (size_t)(K + 1);
@@ -1161,25 +1201,16 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     nb[kth] = nbv[kth];
                     float *row = zr + kth * c;
                     row[0] = zrx[kth]; row[1] = zry[kth];
-                    if (c == 5) {
-                        if (kth == 0) {
-                            row[2] = vxi; row[3] = vyi; row[4] = li;          // :355
-                        } else if (have[kth]) {                               // :367 / :385
-                            const unsigned j = list.index(kth);
-                            float2 vj;
-                            if (rand_act) {                            // counter-based stream: any lane can
-                                uint32_t o[4];                                // restate any agent's action
-                                philox4x32_10(j, gid, (uint32_t)(tcur >> 1), epi, a.key0 ^ kRandActKey, a.key1, o);
-                                vj = (tcur & 1) ? make_float2(unit_action(o[2]), unit_action(o[3]))
-                                                : make_float2(unit_action(o[0]), unit_action(o[1]));
-                            } else {
-                                vj = reinterpret_cast<const float2 *>(velsrc)[(size_t)env * N + j];
-                            }
-                            row[2] = vj.x; row[3] = vj.y; row[4] = uni_args ? a.radius_u : sconst[j].y;
-                        } else {
-                            row[2] = row[3] = row[4] = __builtin_nanf("");
-                        }
-                    }
+                    if (FAR && c == 5) { row[2] = zvx[kth]; row[3] = zvy[kth]; row[4] = zvl[kth]; }
+                }
+            } else if (FAR && zc == 5) {                                      // this lane's 5 (K+1)-word row -> staging area
+                float *zrow5 = reinterpret_cast<float *>(stage_z) + lane * (5 * (K + 1));
+                unsigned *nrow5 = stage_n + lane * kNRow;
+#pragma unroll
+                for (int kth = 0; kth <= K; ++kth) {
+                    zrow5[5 * kth + 0] = zrx[kth]; zrow5[5 * kth + 1] = zry[kth];
+                    zrow5[5 * kth + 2] = zvx[kth]; zrow5[5 * kth + 3] = zvy[kth]; zrow5[5 * kth + 4] = zvl[kth];
+                    nrow5[kth] = (unsigned)nbv[kth];
                 }
             }
 
@@ -1217,7 +1248,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             asm volatile("" :: "v"(acc)); }
         if (false) {
 #else
-        if (staged && valid) {                                // this lane's rows -> the wave's staging area
+        if (staged && valid && zc == 2) {                     // this lane's rows -> the wave's staging area
 #endif
 #pragma unroll
             for (int kth = 0; kth <= K; ++kth) {              // one base each (formed early), immediate offsets
@@ -1240,6 +1271,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
         if (staged && nval > 0) {
 #endif
             g_u32 *gzg = p_gz, *gng = p_gn;
+            if (FAR && zc == 5) gzg = (g_u32 *)(reinterpret_cast<unsigned *>(a.z) + (so + wga0) * (size_t)(5 * (K + 1)));
             unsigned *gz = (unsigned *)gzg, *gn = (unsigned *)gng;              // (generic views for the ragged copy)
             // wave-uniform row bases: pinned in SGPRs so that the stores below address as scalar base + 32-bit lane
             // offset (the compiler otherwise builds 64-bit per-lane addresses: three v_lshl_add_u64 and two v_mad_i64_i32)
@@ -1247,7 +1279,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             gu32x4 *gz4 = (gu32x4 *)gzg, *gn4 = (gu32x4 *)gng;
             // fixed-shape copy: a full wave of agents whose rows start 16-byte aligned -- always for kSym64 (checked on
             // the host), every full wave of the workgroup-per-env geometries otherwise (wave-uniform test)
-            const bool fixed = SYM || (BLOCKGEO && nval == kWave &&
+            const bool fixed = SYM || (BLOCKGEO && !(FAR && zc == 5) && nval == kWave &&
                                        ((reinterpret_cast<uintptr_t>(gz) | reinterpret_cast<uintptr_t>(gn)) & 15u) == 0);
 #if !defined(DRONESIM_TRACE)                                   // (the trace build's stamps make hipcc lose the uniformity)
             if (SYM || BLOCKGEO) asm volatile("" : "+s"(gz4), "+s"(gn4));
@@ -1275,7 +1307,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     if ((r + 1) * 4 * kWave <= nn || (int)lane * 4 < nn - r * 4 * kWave)
                         __builtin_nontemporal_store(vn[r], gn4 + r * kWave + lane);
             } else {
-                wave_copy_out(gz, stage_z, nval * kZRow, lane);
+                wave_copy_out(gz, stage_z, nval * zrow_w, lane);
                 wave_copy_out(gn, stage_n, nval * kNRow, lane);
             }
         }
@@ -2018,7 +2050,7 @@ Geometry geometry(int N, int E)
 }
 
 // dynamic LDS of drone_kernel (must mirror the carve-up in the kernel)
-size_t drone_lds_bytes(const Geometry &g, int N, int k)
+size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2)   // zc: columns of a staged z row (2, or 5 when those fit)
 {
     const size_t nwaves = (size_t)g.threads / kWave;
     const size_t nconst = g.P > 0 ? nwaves : 1;
@@ -2026,7 +2058,7 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k)
     size_t red = 2 * (size_t)g.epb;
     red += (red & 3) ? 4 - (red & 3) : 0;
     b += sizeof(int) * red;
-    b += sizeof(unsigned) * nwaves * kWave * 3 * (size_t)(k + 1);   // z (2 words) + Ni (1 word) per lane
+    b += sizeof(unsigned) * nwaves * kWave * (size_t)(zc + 1) * (size_t)(k + 1);   // z (zc words) + Ni (1 word) per slot and lane
     // bucket filter tables: [2 axes][64 cells][words] per env slot, or kSym64's per-wave rows (whichever is larger)
     const size_t slots = g.P > 0 ? (size_t)g.epb : 1, words = g.P > 0 ? 1 : nwaves;
     const size_t generic = (g.P > 0 && N < kBucketMinN) ? 0 : sizeof(unsigned long long) * slots * 2 * kCells * words;
@@ -2190,10 +2222,22 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
 {
     if (E == 0) return DRONESIM_OK;
     Geometry g = geometry(p->N, E);
+    const bool epi_regions = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;   // the episode layer's regions: only when in use
+    const size_t tail = epi_regions ? drone_lds_tail_bytes(g, p->N) : 0;
     g.lds = drone_lds_bytes(g, p->N, p->k);
+    a.stage5 = 0; a.lds_vel = 0;
+    if (p->c == 5) {
+        // c = 5 rows: staged through LDS like the c = 2 ones, and the agents' velocities kept in LDS for the rows of the k
+        // nearest, when the env's tile still fits (it does up to N = 1024 at k <= 5; the rows leave as 4-byte stores at a
+        // 60-byte stride otherwise, as they all did through round 2)
+        const size_t lds5 = drone_lds_bytes(g, p->N, p->k, 5), vel = sizeof(float2) * (size_t)g.epb * (size_t)p->N;
+        if (lds5 + vel + tail <= 160 * 1024) {
+            a.stage5 = 1; a.lds_vel = (int)lds5; g.lds = lds5 + vel;
+        }
+    }
     a.lds_tail = (int)g.lds;
-    if (a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0) {   // the episode layer's regions: only when it is in use
-        g.lds += drone_lds_tail_bytes(g, p->N);
+    if (epi_regions) {
+        g.lds += tail;
         a.samp_tbl = samp_table_entries(p->N);
         a.samp_shift = 32 - __builtin_ctz((unsigned)a.samp_tbl);
     }
