@@ -76,6 +76,14 @@ enum Mode { kStep = 0, kObserve = 1, kRollout = 2 };
 #else
 #define TRACE_MARK(k) do {} while (0)
 #endif
+// -DDRONESIM_TRACE_FINE moves stamps 1 and 2 into the filter phase of the generic bucket filter (tables built / candidates tested)
+#if defined(DRONESIM_TRACE_FINE)
+#define TRACE_COARSE(k) do {} while (0)
+#define TRACE_FINE(k) TRACE_MARK(k)
+#else
+#define TRACE_COARSE(k) TRACE_MARK(k)
+#define TRACE_FINE(k) do {} while (0)
+#endif
 
 struct KArgs {
     long long *trace;               // developer builds (-DDRONESIM_TRACE) only: per-wave phase timestamps
@@ -767,9 +775,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             bcx = (int)__builtin_floorf(xi * inv_cell) & (kCells - 1);
             bcy = (int)__builtin_floorf(yi * inv_cell) & (kCells - 1);
         }
-        TRACE_MARK(1);
+        TRACE_COARSE(1);
         group_sync<WL>();
-        TRACE_MARK(2);
+        TRACE_COARSE(2);
         if (FAR && step == 0 && a.far_inm && !uniform && valid) {
 #pragma nounroll
             for (int j = 0; j < N; ++j) far_total += (j != agent && dhat <= sconst[j].x) ? 1 : 0;
@@ -781,6 +789,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
             }
             group_sync<WL>();
         }
+        TRACE_FINE(1);                                       // (-DDRONESIM_TRACE_FINE: cell tables built)
 
         // @phase pass2_init
         float zrx[K + 1], zry[K + 1];
@@ -839,10 +848,31 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 }
             }
             const bool crowded = __builtin_expect(__builtin_amdgcn_ballot_w64(npool > kBucketMax) != 0ull, 0);
+            // the first candidate of every word is tested at once (their position reads share one LDS round trip): a
+            // sparse env has about one candidate per lane and word at most, and with two waves per SIMD nothing hides
+            // the dependent trip per candidate -- C5: 1.2 of the wave's 4.1 us went into one-at-a-time tests
+            unsigned long long first[WMAX];
+#pragma unroll
+            for (int w = 0; w < WMAX; ++w) first[w] = 0ull;
+            if (GEO == kBlock256 && !crowded) {
+                float2 pf[WMAX];
+                int uf[WMAX];
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) {
+                    uf[w] = pool[w] ? __builtin_ctzll(pool[w]) : 0;
+                    pf[w] = spos_env[pool[w] ? 64 * w + uf[w] : 0];
+                }
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) {
+                    const float dx = xi - pf[w].x, dy = yi - pf[w].y;
+                    if (pool[w] != 0ull && fmaf(dy, dy, dx * dx) < thr) first[w] = 1ull << uf[w];
+                    pool[w] &= pool[w] - 1ull;
+                }
+            }
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) {
                 if (w < W) {
-                    unsigned long long hits = 0ull;
+                    unsigned long long hits = first[w];
 #if defined(DRONESIM_ABLATE_PASS1)
                     if (true) { hits = (xi == 123.456f) ? 1ull : 0ull; } else
 #endif
@@ -882,9 +912,34 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     pool[w] = hits;                          // the verdicts replace the candidates
                 }
             }
+            TRACE_FINE(2);                                   // (-DDRONESIM_TRACE_FINE: candidates tested)
             // pass 2 over the verdicts, ascending agent order.  Workgroup-per-env geometries (ascending-order list):
             // the hot walk defers the general insertion and is written out for the uniform-(Delta, l) case, like kSym64's
             auto walk = [&](auto defer, auto uni) {
+                if (GEO == kBlock256 && decltype(defer)::value) {
+                    // ONE loop over the verdicts of all words (every lane takes its own lowest partner per trip): a trip
+                    // costs the wave a dependent LDS read and ~60 VALU whatever the number of lanes that take part, and
+                    // the few partners of a sparse env are spread over the words
+                    unsigned long long h[WMAX];
+#pragma unroll
+                    for (int w = 0; w < WMAX; ++w) h[w] = pool[w];
+                    unsigned long long left = 0ull;
+#pragma unroll
+                    for (int w = 0; w < WMAX; ++w) left |= h[w];
+                    while (left != 0ull) {
+                        unsigned long long hs = h[WMAX - 1];
+                        int ws = WMAX - 1;
+#pragma unroll
+                        for (int w = WMAX - 2; w >= 0; --w) { if (h[w] != 0ull) { hs = h[w]; ws = w; } }
+                        const int u = __builtin_ctzll(hs);
+                        hs &= hs - 1ull;
+                        left = 0ull;
+#pragma unroll
+                        for (int w = 0; w < WMAX; ++w) { if (w == ws) h[w] = hs; left |= h[w]; }
+                        visit(64 * ws + u, defer, uni);
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int w = 0; w < WMAX; ++w) {
                     if (w < W) {
