@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DRONESIM_VERSION 300           /* 0.3.0: DroneEpisodeCtl grew z_final / nbr_final / pos_final */
+#define DRONESIM_VERSION 301           /* 0.3.0: DroneEpisodeCtl grew z_final / nbr_final / pos_final */
 #define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
 #define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
 
@@ -263,7 +263,11 @@ typedef struct DroneMlp {
     int32_t N, d_in, h1, h2, nout;
     int32_t out_kind;       /* 0 identity, 1 softmax, 2 tanh(first half) + sigmoid(second half) */
     int32_t sample_kind;    /* 0 none, 1 categorical -> unit-circle action, 2 Gaussian          */
-    int32_t reserved;
+    int32_t w2_layout;      /* 0: w2 = [N][h1][h2] (the reference's layout transposed, like w1 / w3);
+                             * 1: w2 = float32 matrix-core fragments [N][ceil(h2/32)][ceil(h1/16)][2][64][4] with
+                             *    w2[a][c][s][q][l][j] = W2_a[16 s + 8 (l >> 5) + 4 q + j][32 c + (l & 31)], zero beyond
+                             *    h1 / h2 -- packed once per weight update, read with 16-byte coalesced loads (the fast
+                             *    path; what the host class BatchedMLP passes).  Same arithmetic, float32 throughout.  */
     const float *w1, *b1, *w2, *b2, *w3, *b3;
 } DroneMlp;
 int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,

@@ -66,7 +66,7 @@ class DroneParamsF64(C.Structure):
 class DroneMlp(C.Structure):
     """Mirror of `struct DroneMlp` (include/dronesim.h)."""
     _fields_ = [("N", C.c_int32), ("d_in", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("nout", C.c_int32),
-                ("out_kind", C.c_int32), ("sample_kind", C.c_int32), ("reserved", C.c_int32),
+                ("out_kind", C.c_int32), ("sample_kind", C.c_int32), ("w2_layout", C.c_int32),
                 ("w1", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p), ("b2", C.c_void_p),
                 ("w3", C.c_void_p), ("b3", C.c_void_p)]
 

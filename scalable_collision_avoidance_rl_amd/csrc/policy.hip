@@ -67,6 +67,14 @@ struct MArgs {
     FinishArgs fin;
 };
 
+// LDS row stride (floats) of the h1 tile for the packed layer 2: whole 32-column chunks (the k padding is written as
+// zeros by layer 1), a multiple of 4 (16-byte aligned rows) whose quotient is odd (ds_read_b128 phases conflict-free)
+__host__ __device__ __forceinline__ int packed_row_stride(int h1)
+{
+    const int w = ((h1 + 31) >> 5) * 32;
+    return ((w >> 2) & 1) ? w : w + 4;
+}
+
 // Workgroup -> (agent, row block).  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs,
 // each with its own 4 MiB L2; all agents' weights together (12.8 MiB in bf16 / 23 MiB in f32 at N = 64,
 // h = 300) do not fit one L2, a few agents' do.  So the work list is ordered agent-major and cut into 8
@@ -229,8 +237,69 @@ __device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, 
     }
 }
 
+// ---- layer 2 on fragment-packed weights (DroneMlp.w2_layout = 1, what the host class passes) ------------------------
+// One pipeline stage = 16 k-values = 8 MFMAs.  Lane (col = lane & 31, half = lane >> 5) feeds MFMA u of stage s with
+// k = 16 s + 8 half + u: its eight A values are CONSECUTIVE floats of its h1 row in LDS (two ds_read_b128; the row
+// stride is a multiple of 4 floats with an odd quotient, so the 16 lanes of a read phase hit 16 different bank
+// quads), its eight B values two 16-byte pieces of the packed chunk
+//     w2p[agent][chunk c][stage s][q][lane][4] = W2[16 s + 8 half + 4 q + jj][32 c + col]       (zero beyond h1 / h2)
+// which the wave reads as two fully coalesced 1 KiB loads (scalar base + lane * 16 + immediate).  The reference-layout
+// loop above needs 8 dword loads, 4 LDS reads, 16 64-bit address additions and 16 register copies per stage (4 VALU
+// per MFMA -- round-3 counters: 7 VALU instructions per MFMA over the kernel, the matrix pipe 54-60 % busy with two
+// waves per SIMD); this one 2 + 2 loads, no copies (R register sets, the loop unrolled R times) and scalar address
+// updates, with the loads R - 1 stages (R = 3: 1024 matrix cycles) ahead of their use.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct FragSet { f32x4 a0, a1, b0, b1; };
+
+__device__ __forceinline__ void load_set(FragSet &t, const float *Arow, const f32x4 *Bp, int s)
+{
+    const f32x4 *ap = reinterpret_cast<const f32x4 *>(Arow + 16 * s);
+    const f32x4 *bp = Bp + (size_t)s * 128;
+    t.b0 = bp[0]; t.b1 = bp[64];
+    t.a0 = ap[0]; t.a1 = ap[1];
+}
+__device__ __forceinline__ void mfma_set(f32x16 &acc, const FragSet &t)
+{
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.a0[u], t.b0[u], acc, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.a1[u], t.b1[u], acc, 0, 0, 0);
+}
+
+// acc += (h1 tile, stages [sb, sb + n)) x (packed chunk).  Arow: this lane's LDS row + 8 half; Bp: chunk base + lane.
+template <int R>
+__device__ __forceinline__ void tile_gemm_packed(f32x16 &acc, const float *Arow, const f32x4 *Bp, int sb, int n)
+{
+    FragSet set[R];
+    if (n < R - 1) {                                         // (a hidden layer of <= 16 (R - 2) units)
+        for (int s1 = 0; s1 < n; ++s1) { load_set(set[0], Arow, Bp, sb + s1); mfma_set(acc, set[0]); }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < R - 1; ++r) load_set(set[r], Arow, Bp, sb + r);
+    int s = 0;
+    // steady state: R stages per trip, every load unconditional (a conditional one makes hipcc wait for one stage more
+    // than needed at the join, which costs a whole stage of prefetch distance)
+    for (const int last = n - (2 * R - 1); s <= last; s += R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            load_set(set[(r + R - 1) % R], Arow, Bp, sb + s + r + R - 1);
+            mfma_set(acc, set[r]);
+        }
+    }
+    // the last <= 2 R - 2 stages
+#pragma unroll
+    for (int r = 0; r < 2 * R - 2; ++r) {
+        if (s + r < n) {                                     // wave-uniform
+            if (s + r + R - 1 < n) load_set(set[(r + R - 1) % R], Arow, Bp, sb + s + r + R - 1);
+            mfma_set(acc, set[r % R]);
+        }
+    }
+}
+
 // kRows env rows of one agent per workgroup, 4 waves per 32-row tile: wave w owns feature chunks (w & 3),
 // (w & 3) + 4, ... of the rows of tile (w >> 2).
+template <bool PACKED>                   // PACKED: W2 in the fragment layout of tile_gemm_packed
 __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, int N, int d_in, const MArgs rest)
 {
     MArgs a = rest;                      // leading scalars are preloaded into SGPRs at wave launch (csrc/Makefile)
@@ -244,13 +313,15 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     // so that the heavy waves of the two workgroups on a CU sit on different SIMDs, was measured in round 3: +-1 %)
     const int cw = wave & 3, rh = wave >> 2;
     const int e0 = row_block * kRows;
-    const int ldx = a.d_in + 1, ld1 = a.h1 + 1;
+    const int ldx = a.d_in + 1, ld1 = PACKED ? packed_row_stride(a.h1) : a.h1 + 1;
     float *sx = reinterpret_cast<float *>(smem);                 // [rows][d_in+1]
     float *sh1 = sx + kRows * ldx;                               // [rows][h1+1]
     float *sst = sh1 + kRows * ld1;                              // [waves][32][33] layer-2 chunk staging,
                                                                  // reused for the layer-3 partials
     const float *w1 = a.w1 + (size_t)agent * a.d_in * a.h1, *b1 = a.b1 + (size_t)agent * a.h1;
-    const float *w2 = a.w2 + (size_t)agent * a.h1 * a.h2, *b2 = a.b2 + (size_t)agent * a.h2;
+    const int nst = (a.h1 + 15) >> 4;                            // PACKED: 16-k stages of layer 2
+    const float *w2 = a.w2 + (PACKED ? (size_t)agent * ((a.h2 + 31) >> 5) * nst * 512 : (size_t)agent * a.h1 * a.h2);
+    const float *b2 = a.b2 + (size_t)agent * a.h2;
     const float *w3 = a.w3 + (size_t)agent * a.h2 * a.nout, *b3 = a.b3 + (size_t)agent * a.nout;
 
     PT(0);
@@ -291,6 +362,9 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc[r] + bias[i], 0.0f);
+                } else if (PACKED) {                             // the k padding of the last stage reads as zero
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = 0.0f;
                 }
             }
         }
@@ -301,8 +375,10 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
             f32x16 acc = {0};
             tile_gemm(acc, sx + rh * 32 * ldx, ldx, w1 + c0, a.h1, a.d_in, a.h1 - c0, lane);
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
+            for (int r = 0; r < 16; ++r) {
                 if (ok) sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = fmaxf(acc[r] + bias, 0.0f);
+                else if (PACKED) sh1[(rh * 32 + cd_row(r, lane)) * ld1 + c0 + col] = 0.0f;
+            }
         }
     }
     PT(2);
@@ -341,16 +417,21 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     // ONE loop over both kinds of trips (one inlined copy of each GEMM: a second copy of the layer-2 loop took the kernel
     // from 244 to 272 registers, i.e. from two workgroups per CU to one): first the whole rounds, then the leftover chunks
     const int rounds = (nch_even + 3) >> 2;                      // (whole dealing: the last round may be ragged)
-    const int kq = (((a.h1 + 3) >> 2) + 1) & ~1;                 // a quarter of K, even
+    const int kq = PACKED ? 16 * ((nst + 3) >> 2) : (((a.h1 + 3) >> 2) + 1) & ~1;   // a quarter of K (even; PACKED: whole stages)
+    const int kpad = PACKED ? 16 * nst : a.h1;
     for (int it = 0; it < rounds + (nch - nch_even); ++it) {     // wave-uniform trip count (barriers inside)
         const bool left = it >= rounds;                          // leftover chunk: this wave's K quarter of it
         const int c0 = (left ? nch_even + (it - rounds) : cw + 4 * it) * 32;
         if (!left && c0 >= nch_even * 32) continue;              // ragged last round of the whole dealing (no barrier in it)
-        const int kb = left ? min(cw * kq, a.h1) : 0, kn = left ? min(kq, a.h1 - kb) : a.h1;
+        const int kb = left ? min(cw * kq, kpad) : 0, kn = left ? min(kq, kpad - kb) : kpad;
         const bool ok = c0 + col < a.h2;
         const float bias = ok ? b2[c0 + col] : 0.0f;             // issued before the k-loop, needed after it
         f32x16 acc = {0};
-        if (kn > 0)
+        if (PACKED) {
+            if (kn > 0)
+                tile_gemm_packed<3>(acc, sh1 + (rh * 32 + col) * ld1 + 8 * (lane >> 5),
+                                    reinterpret_cast<const f32x4 *>(w2 + (size_t)(c0 >> 5) * nst * 512) + lane, kb >> 4, kn >> 4);
+        } else if (kn > 0)
             tile_gemm(acc, sh1 + rh * 32 * ld1 + kb, ld1, w2 + c0 + (size_t)kb * a.h2, a.h2, kn, a.h2 - c0, lane);
         bool l3 = true;                                          // this wave feeds the chunk to layer 3
         if (!left) {
@@ -1256,16 +1337,22 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2; a.nout = m->nout;
     a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
-    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * (m->h1 + 1) + (kThreadsF / 64) * 32 * 33);
+    if (m->w2_layout != 0 && m->w2_layout != 1) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: w2_layout must be 0 or 1");
+    const bool packed = m->w2_layout == 1;
+    const size_t ld1 = packed ? (size_t)packed_row_stride(m->h1) : (size_t)m->h1 + 1;
+    // (x rows: d_in + 1 floats; the h1 tile follows on a 16-byte boundary)
+    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * ld1 + (kThreadsF / 64) * 32 * 33);
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
     {
         static std::mutex mu;
-        static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
-        const int lrc = enable_big_lds(reinterpret_cast<const void *>(mlp3_kernel), opted, mu, "mlp3_kernel");
+        static unsigned long long opted[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}};
+        const int lrc = enable_big_lds(packed ? reinterpret_cast<const void *>(mlp3_kernel<true>) : reinterpret_cast<const void *>(mlp3_kernel<false>),
+                                       opted[packed ? 1 : 0], mu, "mlp3_kernel");
         if (lrc) return lrc;
     }
-    hipLaunchKernelGGL(mlp3_kernel, dim3(((E + kRows - 1) / kRows) * m->N), dim3(kThreadsF), lds, static_cast<hipStream_t>(stream),
-                       a.x, a.E, a.N, a.d_in, a);
+    const dim3 grid(((E + kRows - 1) / kRows) * m->N);
+    if (packed) hipLaunchKernelGGL(mlp3_kernel<true>, grid, dim3(kThreadsF), lds, static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
+    else hipLaunchKernelGGL(mlp3_kernel<false>, grid, dim3(kThreadsF), lds, static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

@@ -152,14 +152,30 @@ def pack_bf16x3_streams(w1, w2, w3, stages):
     return pack_split_streams(w1, w2, w3, stages, "bf16x3")
 
 
+def pack_f32_fragments(w):
+    """[N, K, F] float32 weights -> float32 matrix-core fragments [N, ceil(F/32), ceil(K/16), 2, 64, 4], the layout
+    `dronesim_mlp_forward` reads with two coalesced 16-byte loads per lane and 16-k stage (`DroneMlp.w2_layout = 1`):
+        frag[a, c, s, q, l, j] = w[a, 16 s + 8 (l >> 5) + 4 q + j, 32 c + (l & 31)]       (zero beyond K / F)"""
+    import torch
+    n, k, f = w.shape
+    ns, nc = (k + 15) // 16, (f + 31) // 32
+    pad = torch.zeros(n, ns * 16, nc * 32, dtype=torch.float32, device=w.device)
+    pad[:, :k, :f] = w
+    # k = 16 s + 8 h + 4 q + j -> axes (s, h, q, j); column = 32 c + i; lane = 32 h + i
+    frag = pad.view(n, ns, 2, 2, 4, nc, 32).permute(0, 5, 1, 3, 2, 6, 4)                  # [N, c, s, q, h, i, j]
+    return frag.reshape(n, nc, ns, 2, 64, 4).contiguous()
+
+
 class BatchedMLP:
-    def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0, precision="f32"):
+    def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0, precision="f32", pack_w2=True):
         """w1 [N,d_in,h1], b1 [N,h1], w2 [N,h1,h2], b2 [N,h2], w3 [N,h2,nout], b3 [N,nout] (float32).
         ``precision="f32"`` (default) is exact float32 on the matrix cores; ``"bf16x3"`` and ``"f16x2"`` give
         float32-accurate results (same 1e-5 bar) from three-part bfloat16 / two-part float16 splits of weights and
         activations on the 16-bit matrix instructions (six / three partial products); f16x2 is the faster one and
         needs every weight, input and hidden activation below 65504 in magnitude; ``"bf16"`` runs weights and
-        activations in plain bfloat16 with float32 accumulation (~1e-2 relative agreement, fastest)."""
+        activations in plain bfloat16 with float32 accumulation (~1e-2 relative agreement, fastest).
+        ``pack_w2`` (f32 only): hand layer 2's weights to the kernel as matrix-core fragments (`pack_f32_fragments`,
+        the fast path); False keeps the [N, h1, h2] array of the plain C ABI (`DroneMlp.w2_layout = 0`)."""
         import torch
         from . import _native
         self._torch, self._native = torch, _native
@@ -181,6 +197,10 @@ class BatchedMLP:
         m.b2, m.w3, m.b3 = self.b2.data_ptr(), self.w3.data_ptr(), self.b3.data_ptr()
         self._m = m
         self.precision = precision
+        if precision == "f32" and pack_w2:
+            # layer 2 (all but a few per cent of the arithmetic) reads its weights as matrix-core fragments
+            self._w2p = pack_f32_fragments(self.w2)
+            m.w2, m.w2_layout = self._w2p.data_ptr(), 1
         if precision == "bf16":
             if self.d_in > 16:
                 raise ValueError("the bf16 path supports d_in <= 16")

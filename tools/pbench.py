@@ -23,7 +23,8 @@ def rnd_policy(kind, N, d, dev, precision="f32"):
         h1 = h2 = 400; nout = 4; ok, sk = 2, 2
     else:
         h1 = h2 = 200; nout = 1; ok, sk = 0, 0
-    return BatchedMLP(r(N, d, h1), r(N, h1), r(N, h1, h2), r(N, h2), r(N, h2, nout), r(N, nout), ok, sk, device=dev, precision=precision), (h1, h2, nout)
+    return BatchedMLP(r(N, d, h1), r(N, h1), r(N, h1, h2), r(N, h2), r(N, h2, nout), r(N, nout), ok, sk, device=dev, precision=precision,
+                      pack_w2=os.environ.get("PB_PACK", "1") != "0"), (h1, h2, nout)   # PB_PACK=0: the plain [N, h1, h2] layer 2
 
 
 def timeit(fn, steps=20, reps=5):
