@@ -247,7 +247,13 @@ __device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, 
 // loop above needs 8 dword loads, 4 LDS reads, 16 64-bit address additions and 16 register copies per stage (4 VALU
 // per MFMA -- round-3 counters: 7 VALU instructions per MFMA over the kernel, the matrix pipe 54-60 % busy with two
 // waves per SIMD); this one 2 + 2 loads, no copies (R register sets, the loop unrolled R times) and scalar address
-// updates, with the loads R - 1 stages (R = 3: 1024 matrix cycles) ahead of their use.
+// updates, with the loads R - 1 stages ahead of their use.  Measured at the C5 shard (Gaussian actor, h = 400):
+// reference layout 521 us; R = 1 / 2 / 3 / 4: 505 / 417-424 / 436-445 / 460 us -- one stage (512 matrix cycles) of
+// distance is enough with a second wave on the SIMD, deeper only keeps more loads and registers in flight.  Requesting
+// the next chunk's first stages and the chunk's W3 rows early (across the layer-3 part) was measured too: +-1 %.
+#ifndef POLICY_SETS
+#define POLICY_SETS 2         // register sets of the pipeline (see tile_gemm_packed)
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct FragSet { f32x4 a0, a1, b0, b1; };
 
@@ -429,7 +435,7 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
         f32x16 acc = {0};
         if (PACKED) {
             if (kn > 0)
-                tile_gemm_packed<3>(acc, sh1 + (rh * 32 + col) * ld1 + 8 * (lane >> 5),
+                tile_gemm_packed<POLICY_SETS>(acc, sh1 + (rh * 32 + col) * ld1 + 8 * (lane >> 5),
                                     reinterpret_cast<const f32x4 *>(w2 + (size_t)(c0 >> 5) * nst * 512) + lane, kb >> 4, kn >> 4);
         } else if (kn > 0)
             tile_gemm(acc, sh1 + rh * 32 * ld1 + kb, ld1, w2 + c0 + (size_t)kb * a.h2, a.h2, kn, a.h2 - c0, lane);
