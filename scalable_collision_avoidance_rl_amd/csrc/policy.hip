@@ -417,6 +417,8 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     // balance gains (+1.5 % / +19 %), so those deal their chunks whole as before
 #if defined(POLICY_NO_KSPLIT)
     const int nch_even = nch;
+#elif defined(POLICY_KSPLIT_ALL)
+    const int nch_even = nch & ~3;
 #else
     const int nch_even = (nch & 3) == 1 ? (nch & ~3) : nch;
 #endif
