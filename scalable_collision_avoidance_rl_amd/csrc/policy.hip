@@ -1337,6 +1337,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     if (rc) return rc;
     if (!m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3)
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
+    if (m->w2_layout != 0 && m->w2_layout != 1) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: w2_layout must be 0 or 1");
     if (E == 0) return DRONESIM_OK;
     MArgs a{};
 #if defined(DRONESIM_TRACE)
@@ -1345,7 +1346,6 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2; a.nout = m->nout;
     a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
-    if (m->w2_layout != 0 && m->w2_layout != 1) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: w2_layout must be 0 or 1");
     const bool packed = m->w2_layout == 1;
     const size_t ld1 = packed ? (size_t)packed_row_stride(m->h1) : (size_t)m->h1 + 1;
     // (x rows: d_in + 1 floats; the h1 tile follows on a 16-byte boundary)

@@ -171,6 +171,18 @@ def test_split_policy_boundary_without_a_gpu():
         assert err == 0.0 if scheme == "bf16x3" else err < 2.0 ** -21
 
 
+def test_mlp_forward_validates_w2_layout_before_any_hip_call():
+    lib = _native.lib()
+    m = _native.DroneMlp()
+    m.N, m.d_in, m.h1, m.h2, m.nout, m.out_kind, m.sample_kind = 2, 6, 40, 72, 4, 0, 0
+    one = C.c_void_p(16)                                          # any non-NULL address: validation never dereferences
+    m.w1 = m.b1 = m.w2 = m.b2 = m.w3 = m.b3 = one
+    for layout, want in ((0, _native.OK), (1, _native.OK), (2, _native.EINVAL), (-1, _native.EINVAL)):
+        m.w2_layout = layout
+        assert lib.dronesim_mlp_forward(C.byref(m), one, None, None, None, 0, 0, 0, None, None, 0, None) == want   # E = 0
+    assert b"w2_layout" in lib.dronesim_last_error()
+
+
 def test_pack_f32_fragments_layout():
     """`pack_f32_fragments` lays layer 2's float32 weights out as include/dronesim.h states for DroneMlp.w2_layout = 1:
     frag[a][c][s][q][l][j] = W[a][16 s + 8 (l >> 5) + 4 q + j][32 c + (l & 31)], zero beyond K / F."""
