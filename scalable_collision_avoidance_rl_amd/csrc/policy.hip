@@ -251,6 +251,10 @@ __device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, 
 // reference layout 521 us; R = 1 / 2 / 3 / 4: 505 / 417-424 / 436-445 / 460 us -- one stage (512 matrix cycles) of
 // distance is enough with a second wave on the SIMD, deeper only keeps more loads and registers in flight.  Requesting
 // the next chunk's first stages and the chunk's W3 rows early (across the layer-3 part) was measured too: +-1 %.
+// Per-wave trace of this kernel (tools/trace_policy.py gaussian c5 f32): layer 2 is 72 % of a wave's life, layer 1 20 %
+// (8.4k ticks waiting for W1 / b1 / x, 13.7k for ~200 instructions: while the OTHER workgroup's wave on the SIMD streams
+// matrix instructions, this one gets about one issue slot per matrix instruction); raising the issue priority of the
+// waves outside their layer-2 loop (s_setprio 2 / 3) costs 2.4 % instead of helping.  Matrix pipe busy 70 % (54 %).
 #ifndef POLICY_SETS
 #define POLICY_SETS 2         // register sets of the pipeline (see tile_gemm_packed)
 #endif
@@ -356,6 +360,10 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
                 bias[i] = c0 + col < a.h1 ? b1[c0 + col] : 0.0f;
             }
         }
+#if defined(DRONESIM_TRACE)
+        __builtin_amdgcn_s_waitcnt(0x0070);                      // trace builds: stamp 7 = layer 1's operands have arrived
+        PT(7);
+#endif
 #pragma unroll
         for (int i = 0; i < kL1; ++i) {
             const int c0 = cw * 32 + 128 * i;

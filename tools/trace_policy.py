@@ -44,6 +44,10 @@ for k in range(1, last + 1):
     d = t[:, :, k] - t[:, :, k - 1]
     per = " ".join(f"w{w}:{np.median(d[:, w]):7.0f}" for w in range(4))
     print(f"  {names[k]:>24}: median {np.median(d):8.0f}  p95 {np.percentile(d, 95):8.0f}   {per}")
+if prec == "f32":                                   # stamp 7: layer 1's operands (W1, b1, x tile from LDS) have arrived
+    d = (t[:, :, 7] - t[:, :, 1])[t[:, :, 7] > 0]
+    if d.size:
+        print(f"  {'of layer 1: operand wait':>24}: median {np.median(d):8.0f}  p95 {np.percentile(d, 95):8.0f}")
 d = (t[:, :, last + 1] - t[:, :, last])[t[:, :, last + 1] > 0]
 print(f"  {names[last + 1]:>24}: median {np.median(d):8.0f}  p95 {np.percentile(d, 95):8.0f}")
 span = t.max() - t[:, :, 0].min()
