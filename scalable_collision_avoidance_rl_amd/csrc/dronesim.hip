@@ -383,6 +383,10 @@ constexpr uint32_t kRandActKey = 0x52414E44u;   // "RAND": separates the action 
 //              ballot), halving the far-filter arithmetic.
 //   kBlock256 / kBlock1024 : N > 64, one workgroup per env, thread = agent.
 enum Geo { kPacked = 0, kSym64 = 1, kBlock256 = 2, kBlock1024 = 3 };
+#if !defined(DRONESIM_SYM_WAVES)
+#define DRONESIM_SYM_WAVES 8
+#endif
+constexpr int kSymStepWaves = DRONESIM_SYM_WAVES;
 
 template <int GEO> struct GeoTraits {
 #if defined(DRONESIM_WG_THREADS)      // developer experiment: waves per workgroup of the wave-local geometries
@@ -390,10 +394,16 @@ template <int GEO> struct GeoTraits {
 #else
     static constexpr int kMaxThreads = GEO == kBlock1024 ? 1024 : 256;
 #endif
-    // C3 needs 4 resident waves per SIMD (4096 envs = 4096 waves on 1024 SIMDs): cap the register budget at 128
-    static constexpr int kMinWavesPerSimd = GEO == kBlock1024 ? 1 : 4;
+    // C3 needs 4 resident waves per SIMD (4096 envs = 4096 waves on 1024 SIMDs): cap the register budget at 128.
+    // kSym64 single-step launches: 64 registers and < 5 KiB of LDS per wave, so that 8 waves per SIMD are resident and a
+    // launch of up to 8192 envs runs in one generation (the fused rollout keeps its 112-128 registers: LICM of a 200-step
+    // loop, and its launches never hold more than 4096 envs per 4 waves anyway)
+    static constexpr int min_waves(int mode) { return GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves : 4; }
     static constexpr bool kWaveLocal = GEO == kPacked || GEO == kSym64;
 };
+
+// kSym64's LDS block per wave: [64 positions][staging: 64 x (z row + Ni row)][x cells | y cells] -- see the carve-up
+constexpr int sym_wave_bytes(int K) { return 64 * 8 + 64 * 3 * (K + 1) * 4 + 2 * kCells * 8; }
 
 template <bool WAVE_LOCAL>
 __device__ __forceinline__ void group_sync()
@@ -415,7 +425,7 @@ constexpr int kKArgsOffset = 2 * 8 + 4 * 4;
 static_assert(kKArgsOffset % alignof(KArgs) == 0, "KArgs sits right behind the leading scalar arguments");
 
 template <int K, bool FAR, int MODE, int GEO, bool EPI>
-__global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::kMinWavesPerSimd) drone_kernel(
+__global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::min_waves(MODE)) drone_kernel(
     // The first 8 dwords of the kernel arguments are preloaded into SGPRs at wave launch (Makefile:
     // -amdgpu-kernarg-preload-count=8; only leading scalar arguments qualify, not the struct): exactly what a
     // wave needs to issue its pos / act loads, which therefore no longer wait for a kernel-argument fetch
@@ -627,6 +637,14 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // c = 2: [64][kZRow] z words + [64][kNRow] Ni words per wave; FAR with staged c = 5 rows: 5 (K+1) z words per lane
     const int zrow_w = (FAR && a.stage5) ? 5 * (K + 1) : kZRow;
     unsigned *stage_z = sstage + (size_t)wave * kWave * (zrow_w + kNRow);
+    // kSym64 (uniform constants, one env per wave) has its own, smaller carve-up: one block per wave of
+    // [64 positions | staging area | x cells | y cells] = sym_wave_bytes(K) (3840 B at k = 2: with the episode layer's
+    // tail 9.5 KiB per two-wave workgroup, 16 workgroups = 8 waves per SIMD per CU).  No (Delta_j, l_j) table, no per-env
+    // verdict words; the doubled / shifted position copies of the crowded fallback, which only it reads, run on from the
+    // 64 positions INTO the staging area (and, for k = 1, the cell tables, which are dead by then): the staging area is
+    // not written before the epilogue, and the rows' neighbour positions are read from the first 64 entries only.
+    char *const sym_block = smem + (size_t)wave * sym_wave_bytes(K);
+    if (SYM) stage_z = reinterpret_cast<unsigned *>(sym_block + 64 * 8);
     unsigned *stage_n = stage_z + kWave * zrow_w;
     float2 *sconst = sconst_all + (WL ? (size_t)wave * (N + (N & 1)) : 0);
     // bucket filter tables.  kSym64: per wave, cell -> lane mask, entries -1..64 of (x mask, y mask).
@@ -637,7 +655,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     // table and reads cells c-1, c, c+1 without a guard row or an edge test.  (Round 2 kept (x, y) pairs at a 16-byte
     // stride: cells c and c + 8 then shared their banks -- 2-3 way conflicts on the ds_or / ds_read of every launch,
     // 40 % of the kernel's LDS cycles; at 8 bytes per cell the 23 cells of C3 are conflict-free.)
-    unsigned long long *sbx = sbt_all + (size_t)wave * (2 * kCells), *sby = sbx + kCells;
+    unsigned long long *sbx = SYM ? reinterpret_cast<unsigned long long *>(sym_block + 64 * 8 + 64 * 3 * (K + 1) * 4)
+                                  : sbt_all + (size_t)wave * (2 * kCells);
+    unsigned long long *sby = sbx + kCells;
     const int W = BLOCKGEO ? nwaves : 1;
     const bool use_bucket = !SYM && (BLOCKGEO || a.bucket != 0);                           // launch-uniform
     unsigned long long *sbt = sbt_all + (size_t)slot * (2 * kCells) * W;                   // this lane's env
@@ -664,7 +684,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
     const float reach = SYM ? a.reach_max : dhat + li + a.radius_max;
     float thr = reach * reach * 1.000001f;                   // early-out radius^2 (conservative)
     float log2_dhat = __builtin_amdgcn_logf(dhat);           // v_log_f32 = log2
-    float2 *spos_env = spos + (size_t)slot * 2 * stride;     // S0 of this lane's env
+    float2 *spos_env = SYM ? reinterpret_cast<float2 *>(sym_block) : spos + (size_t)slot * 2 * stride;   // S0 of this lane's env
     // pass-1 window of this lane starts at dup index agent + (odd r): pick the copy where that is even
     const float2 *pwin = (agent & 1) ? spos_env + agent + 1 : spos_env + stride + agent + 2;
     const int nsteps = (MODE == kRollout) ? a.T : 1;
@@ -1030,18 +1050,21 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                     spos_env[stride + agent + N + 1] = make_float2(xi, yi);
                     group_sync<true>();
                     unsigned mf = 0u, mb = 0u;
+                    // (8 partners in flight, not 16: this rare path must not set the register budget of the hot one --
+                    // with 16 the 64-register step kernels of the episode layer spilled here)
+                    constexpr int kSymChunk = 8;
 #pragma unroll
-                    for (int c2 = 0; c2 < 2; ++c2) {
-                        const float4 *pp = reinterpret_cast<const float4 *>(pwin + c2 * kChunk);   // dup index agent+1+16*c2
-                        float2 pj[kChunk];
+                    for (int c2 = 0; c2 < 32 / kSymChunk; ++c2) {
+                        const float4 *pp = reinterpret_cast<const float4 *>(pwin + c2 * kSymChunk);   // dup index agent+1+8*c2
+                        float2 pj[kSymChunk];
 #pragma unroll
-                        for (int u = 0; u < kChunk / 2; ++u) {            // ds_read_b128: two partners per read
+                        for (int u = 0; u < kSymChunk / 2; ++u) {         // ds_read_b128: two partners per read
                             const float4 v = pp[u];
                             pj[2 * u] = make_float2(v.x, v.y); pj[2 * u + 1] = make_float2(v.z, v.w);
                         }
 #pragma unroll
-                        for (int u = 0; u < kChunk; ++u) {
-                            const int r = 1 + c2 * kChunk + u;                // 1..32
+                        for (int u = 0; u < kSymChunk; ++u) {
+                            const int r = 1 + c2 * kSymChunk + u;             // 1..32
                             const float dx = xi - pj[u].x, dy = yi - pj[u].y;
                             const float d2 = fmaf(dy, dy, dx * dx);
                             const bool f = d2 < thr_list;
@@ -1344,8 +1367,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::k
                 // (a branch-free variant -- surplus lanes of a ragged last round repeating a live lane's 16 bytes, so
                 // that the kernel's tail is one basic block -- was 0.14 us slower per launch: the stores got wider)
                 // All staged words are read before the first store is issued (one LDS round trip for the whole copy-out;
-                // the surplus lanes of a ragged last round read on into the next wave's staging area or the bucket tables
-                // behind it -- at least 4 KiB, allocated in every kSym64 launch -- and store nothing).
+                // the surplus lanes of a ragged last round read on into the cell tables behind the staging area -- kSym64:
+                // the wave's own, part of its block; workgroup-per-env: the env's -- and store nothing).
                 constexpr int nz = kWave * kZRow, nn = kWave * kNRow;          // words
                 constexpr int rz = (nz + 4 * kWave - 1) / (4 * kWave), rn = (nn + 4 * kWave - 1) / (4 * kWave);
                 u32x4 vz[rz], vn[rn];
@@ -2277,9 +2300,21 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
 {
     if (E == 0) return DRONESIM_OK;
     Geometry g = geometry(p->N, E);
+    // far agents matter when a z row carries (v, l) of a tie-ordered agent (c = 5) or
+    // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)
+    const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
+    a.uniform = (p->d_hat_min == p->d_hat_max && p->delta_min == p->delta_max && p->radius_min == p->radius_max) ? 1 : 0;
+#if defined(DRONESIM_NO_UNIFORM)
+    a.uniform = 0;
+#endif
+#if !defined(DRONESIM_NO_SYM64)
+    if (p->N == 64 && !far && a.uniform && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
+        g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane; uniform (d_hat, Delta, radius) only
+#endif
     const bool epi_regions = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;   // the episode layer's regions: only when in use
     const size_t tail = epi_regions ? drone_lds_tail_bytes(g, p->N) : 0;
-    g.lds = drone_lds_bytes(g, p->N, p->k);
+    // kSym64 has its own carve-up: one block per wave (positions, staging area, cell tables)
+    g.lds = g.geo == kSym64 ? (size_t)(g.threads / kWave) * sym_wave_bytes(p->k) : drone_lds_bytes(g, p->N, p->k);
     a.stage5 = 0; a.lds_vel = 0;
     if (p->c == 5) {
         // c = 5 rows: staged through LDS like the c = 2 ones, and the agents' velocities kept in LDS for the rows of the k
@@ -2305,21 +2340,10 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     a.dt = p->dt; a.q = p->q; a.b = p->b; a.done_radius = p->done_radius;
     a.ghost_factor = p->ghost_factor; a.radius_max = p->radius_max;
     a.reach_max = p->d_hat_max + 2.0f * p->radius_max;
-    a.uniform = (p->d_hat_min == p->d_hat_max && p->delta_min == p->delta_max && p->radius_min == p->radius_max) ? 1 : 0;
     a.dhat_u = p->d_hat_max; a.delta_u = p->delta_max; a.radius_u = p->radius_max;
-#if defined(DRONESIM_NO_UNIFORM)
-    a.uniform = 0;
-#endif
     a.xF = p->xF; a.xF_lo = p->xF_lo; a.d_hat = p->d_hat; a.delta = p->delta; a.radius = p->radius;
-    // far agents matter when a z row carries (v, l) of a tie-ordered agent (c = 5) or
-    // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)
-    const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
     a.bucket = (g.P > 0 && p->N >= kBucketMinN) ? 1 : 0;
     a.far_inm = !(p->delta_max < p->d_hat_min) ? 1 : 0;
-#if !defined(DRONESIM_NO_SYM64)
-    if (p->N == 64 && !far && a.uniform && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
-        g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane; uniform (d_hat, Delta, radius) only
-#endif
     hipStream_t s = static_cast<hipStream_t>(stream);
 #if DRONESIM_PART == 0
     static_assert(DRONESIM_MAX_K == 8, "eight parts, one k value each");
