@@ -680,6 +680,19 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     }
 
     if (SYM && MODE != kRollout) { sbx[lane] = 0ull; sby[lane] = 0ull; }   // (the fused rollout zeroes them per rebuild)
+    // Workgroup-per-env, single step: the cell tables are zeroed HERE and the barrier that orders the zeroing (and the
+    // words above) against the other waves' atomics is taken in the shadow of the state loads -- an LDS-only barrier
+    // (__syncthreads() carries a release fence, i.e. a vmcnt(0) wait for the loads in flight).  One barrier instead of
+    // two, and no zeroing loop, between the loads' return and the first mask read.
+#if defined(DRONESIM_NO_EARLY_TABLES)
+    constexpr bool EARLY_TABLES = false;
+#else
+    constexpr bool EARLY_TABLES = BLOCKGEO && MODE != kRollout;
+#endif
+    if (EARLY_TABLES) {
+        for (int o = tid; o < 2 * kCells * W; o += blockDim.x) sbt_all[o] = 0ull;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 
     const float reach = SYM ? a.reach_max : dhat + li + a.radius_max;
     float thr = reach * reach * 1.000001f;                   // early-out radius^2 (conservative)
@@ -791,12 +804,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         int bcx = 0, bcy = 0;
         if (use_bucket) {
             if (WL) { for (int o = lane; o < a.P * 2 * kCells; o += kWave) sbt_all[(size_t)wave * a.P * 2 * kCells + o] = 0ull; }
-            else { for (int o = tid; o < 2 * kCells * W; o += blockDim.x) sbt_all[o] = 0ull; }
+            else if (!EARLY_TABLES) { for (int o = tid; o < 2 * kCells * W; o += blockDim.x) sbt_all[o] = 0ull; }
             bcx = (int)__builtin_floorf(xi * inv_cell) & (kCells - 1);
             bcy = (int)__builtin_floorf(yi * inv_cell) & (kCells - 1);
         }
         TRACE_COARSE(1);
-        group_sync<WL>();
+        if (!EARLY_TABLES) group_sync<WL>();                 // (EARLY_TABLES: taken ahead of the loads' return)
         TRACE_COARSE(2);
         if (FAR && step == 0 && a.far_inm && !uniform && valid) {
 #pragma nounroll
@@ -1337,7 +1350,14 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             for (int kth = 0; kth <= K; ++kth) *(lds_u32 *)(nrow_a + 4 * kth) = (unsigned)nbv[kth];
         }
         TRACE_MARK(4);
+        // the staged rows are written and copied out by the SAME wave: a wave-level fence orders them.  The workgroup
+        // barrier the env's verdict words need (n_coll / done / reward partials of all waves) comes behind the copy-out,
+        // so that a wave's output stores are issued before it waits for the slower waves of its env
+#if defined(DRONESIM_BARRIER_FIRST)
         group_sync<WL>();
+#else
+        group_sync<true>();
+#endif
 #if !defined(DRONESIM_ABL_NOSUM)
         if (WL && !SYM && has_acc) {
             r_env = segment_sum(r_out, agent, N); tr_env = segment_sum(tr_out, agent, N);
@@ -1389,6 +1409,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 wave_copy_out(gn, stage_n, nval * kNRow, lane);
             }
         }
+#if !defined(DRONESIM_BARRIER_FIRST)
+        if (!WL) group_sync<false>();
+#endif
         // @phase env_outputs
         bool fin_env = false;                                 // agent 0: this env's episode ended with this step
         if (SYM) {
