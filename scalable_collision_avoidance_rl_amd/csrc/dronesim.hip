@@ -387,6 +387,14 @@ enum Geo { kPacked = 0, kSym64 = 1, kBlock256 = 2, kBlock1024 = 3 };
 #define DRONESIM_SYM_WAVES 8
 #endif
 constexpr int kSymStepWaves = DRONESIM_SYM_WAVES;
+#if !defined(DRONESIM_BLOCK_WAVES)
+#define DRONESIM_BLOCK_WAVES 8
+#endif
+constexpr int kBlockStepWaves = DRONESIM_BLOCK_WAVES;
+#if !defined(DRONESIM_BLOCK_WAVES_EPI)
+#define DRONESIM_BLOCK_WAVES_EPI 6
+#endif
+constexpr int kBlockStepWavesEpi = DRONESIM_BLOCK_WAVES_EPI;   // (8 makes the episode-layer kernels spill on the hot path)
 
 template <int GEO> struct GeoTraits {
 #if defined(DRONESIM_WG_THREADS)      // developer experiment: waves per workgroup of the wave-local geometries
@@ -398,10 +406,22 @@ template <int GEO> struct GeoTraits {
     // kSym64 single-step launches: 64 registers and < 5 KiB of LDS per wave, so that 8 waves per SIMD are resident and a
     // launch of up to 8192 envs runs in one generation (the fused rollout keeps its 112-128 registers: LICM of a 200-step
     // loop, and its launches never hold more than 4096 envs per 4 waves anyway)
-    static constexpr int min_waves(int mode) { return GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves : 4; }
+    // (the neighbour list, the rows and their staging grow with k: the 64-register budget holds without spills for
+    // k <= 2 -- every BASELINE config --, 80 registers for k <= 4, the round-2 budget of 128 beyond;
+    // tools/kernel_resources.py lists registers / scratch of every instantiation of a built library)
+    // (FAR: the c = 5 rows and the far tail want registers too -- at 64 the C5-sized default construction was 7.6 % slower)
+    static constexpr int min_waves(int k, int mode, bool epi, bool far)
+    {
+        const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves
+                                     : (GEO == kBlock256 && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves) : 4;
+        const int cap = k <= 2 ? 8 : k <= 4 ? 6 : 4;
+        return want < cap ? want : cap;
+    }
     static constexpr bool kWaveLocal = GEO == kPacked || GEO == kSym64;
 };
 
+// workgroup-per-env geometries: float2 entries of the position tile (N, the over-read slack, even for 16-byte alignment)
+__host__ __device__ constexpr int block_pos_entries(int N) { return (N + kPad + 1) & ~1; }
 // kSym64's LDS block per wave: [64 positions][staging: 64 x (z row + Ni row)][x cells | y cells] -- see the carve-up
 constexpr int sym_wave_bytes(int K) { return 64 * 8 + 64 * 3 * (K + 1) * 4 + 2 * kCells * 8; }
 
@@ -425,7 +445,7 @@ constexpr int kKArgsOffset = 2 * 8 + 4 * 4;
 static_assert(kKArgsOffset % alignof(KArgs) == 0, "KArgs sits right behind the leading scalar arguments");
 
 template <int K, bool FAR, int MODE, int GEO, bool EPI>
-__global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::min_waves(MODE)) drone_kernel(
+__global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::min_waves(K, MODE, EPI, FAR)) drone_kernel(
     // The first 8 dwords of the kernel arguments are preloaded into SGPRs at wave launch (Makefile:
     // -amdgpu-kernarg-preload-count=8; only leading scalar arguments qualify, not the struct): exactly what a
     // wave needs to issue its pos / act loads, which therefore no longer wait for a kernel-argument fetch
@@ -630,7 +650,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     const int stride = 2 * N + kPad;                         // float2 per copy (even)
     const int nconst = WL ? nwaves : 1;
     float2 *spos = reinterpret_cast<float2 *>(smem);                                       // [epb][2][stride]
-    float2 *sconst_all = spos + (size_t)a.epb * 2 * stride;                                // [nconst][N + (N&1)]
+    // (workgroup-per-env: always the bucket filter, so only the N positions themselves -- read by agent index -- plus the
+    // slack the crowded path's 16-partner reads may run into: 2.2 instead of 8.5 KB at N = 256)
+    float2 *sconst_all = spos + (BLOCKGEO ? (size_t)block_pos_entries(N) : (size_t)a.epb * 2 * stride);   // [nconst][N + (N&1)]
     int *sred = reinterpret_cast<int *>(sconst_all + (size_t)nconst * (N + (N & 1)));      // [epb][2]
     const int nred = 2 * a.epb + ((2 * a.epb) & 3 ? 4 - ((2 * a.epb) & 3) : 0);
     unsigned *sstage = reinterpret_cast<unsigned *>(sred + nred);
@@ -2155,7 +2177,8 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2)   // zc: col
 {
     const size_t nwaves = (size_t)g.threads / kWave;
     const size_t nconst = g.P > 0 ? nwaves : 1;
-    size_t b = sizeof(float2) * ((size_t)g.epb * 2 * (2 * (size_t)N + kPad) + nconst * ((size_t)N + (N & 1)));
+    size_t b = sizeof(float2) * ((g.P > 0 ? (size_t)g.epb * 2 * (2 * (size_t)N + kPad) : (size_t)block_pos_entries(N)) +
+                                 nconst * ((size_t)N + (N & 1)));
     size_t red = 2 * (size_t)g.epb;
     red += (red & 3) ? 4 - (red & 3) : 0;
     b += sizeof(int) * red;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Registers / scratch / LDS of every kernel in a built libdronesim.so (or object file): finds the gfx950 code objects in
+the clang offload bundles and reads their metadata notes with llvm-readelf.
+
+    python tools/kernel_resources.py [lib.so] [--scratch-only]"""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(blob):
+    pos = 0
+    while True:
+        pos = blob.find(MAGIC, pos)
+        if pos < 0:
+            return
+        n, = struct.unpack_from("<Q", blob, pos + len(MAGIC))
+        q = pos + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, q)
+            triple = blob[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if "gfx" in triple and size:
+                yield triple, blob[pos + off:pos + off + size]
+        pos = q
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    path = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                             "scalable_collision_avoidance_rl_amd", "libdronesim.so")
+    scratch_only = "--scratch-only" in sys.argv
+    blob = open(path, "rb").read()
+    for triple, co in code_objects(blob):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co); f.flush()
+            txt = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True).stdout
+        for blk in txt.split("  - .agpr_count")[1:]:
+            g = lambda k: (re.search(r"\." + k + r":\s+(\S+)", blk) or [None, "?"])[1]
+            name = g("name")
+            m = re.search(r"drone_kernelILi(\d)ELb(\d)ELi(\d)ELi(\d)ELb(\d)", name)
+            short = ("drone_kernel<K=%s,FAR=%s,MODE=%s,GEO=%s,EPI=%s>" % m.groups()) if m else name[:60]
+            if scratch_only and g("private_segment_fixed_size") == "0":
+                continue
+            print(f"{short:48s} vgpr {g('vgpr_count'):>4s} sgpr {g('sgpr_count'):>4s} scratch {g('private_segment_fixed_size'):>5s}"
+                  f" static-lds {g('group_segment_fixed_size'):>6s}")
+
+
+if __name__ == "__main__":
+    main()
