@@ -413,7 +413,8 @@ template <int GEO> struct GeoTraits {
     static constexpr int min_waves(int k, int mode, bool epi, bool far)
     {
         const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves
-                                     : (GEO == kBlock256 && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves) : 4;
+                                     : (GEO == kBlock256 && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
+                                     : (GEO == kBlock256 && epi) ? 3 : 4;   // (the block rollout with the episode layer spilled at 128 registers)
         const int cap = k <= 2 ? 8 : k <= 4 ? 6 : 4;
         return want < cap ? want : cap;
     }
@@ -695,7 +696,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         if (!uni_args && (int)lane < N)
             sconst[lane] = uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[lane], a.radius[lane]);
     } else {
-        if (tid < 2) sred[tid] = 0;
+        if (tid < 4) sred[tid] = 0;                          // (collisions, outside-the-goal flag, CACHED_B's "moved" flag, spare)
         if (!uni_args)
             for (int s = tid; s < N; s += blockDim.x)
                 sconst[s] = uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[s], a.radius[s]);
@@ -736,11 +737,21 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // they were taken -- by the triangle inequality every pair inside `reach` is then still on the list.
     // Outputs are bit-identical to filtering every step: listed pairs beyond `reach` are skipped by the
     // exact test in pass 2.
-    constexpr bool CACHED = SYM && MODE == kRollout;
+    // (round 3: also the workgroup-per-env rollout of up to 256 agents, CACHED_B -- same list, one 64-bit word per 64
+    // partners, the "somebody moved" verdict agreed through an LDS word at the step's first barrier)
+#if defined(DRONESIM_NO_BLOCK_CACHE)
+    constexpr bool CACHED_B = false;
+#else
+    constexpr bool CACHED_B = GEO == kBlock256 && MODE == kRollout && !FAR;
+#endif
+    constexpr bool CACHED = (SYM && MODE == kRollout) || CACHED_B;
     const float thr_list = CACHED ? (reach + a.skin) * (reach + a.skin) * 1.000001f : thr;
     const float moved2 = 0.49f * a.skin * 0.49f * a.skin;
-    const float inv_cell = __builtin_amdgcn_rcpf((CACHED ? reach + a.skin : a.reach_max) * 1.001f);   // bucket filter: cells a little wider than the list radius
+    const float inv_cell = __builtin_amdgcn_rcpf((CACHED ? (SYM ? reach : a.reach_max) + a.skin : a.reach_max) * 1.001f);   // bucket filter: cells a little wider than the list radius
     unsigned long long cand = 0ull;
+    unsigned long long candw[CACHED_B ? WMAX : 1];           // CACHED_B: the listed partners, one word per 64 agents
+#pragma unroll
+    for (int w = 0; w < (CACHED_B ? WMAX : 1); ++w) candw[w] = 0ull;
     float refx = __builtin_nanf(""), refy = refx;            // NaN = no list yet
     // self entry: d_ii = min(-2 l_i, dhat_i), ratio 1 -> log 0, never a collision (:323-325); N_delta[i,i] uses Delta_i (:346)
     float dii = fminf(-li - li, dhat);
@@ -830,14 +841,21 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             bcx = (int)__builtin_floorf(xi * inv_cell) & (kCells - 1);
             bcy = (int)__builtin_floorf(yi * inv_cell) & (kCells - 1);
         }
+        if (CACHED_B) {                                      // has any agent of the env left its skin/2 disk (or no list yet)?
+            const float mx = xi - refx, my = yi - refy;
+            const bool mv = valid && !(fmaf(my, my, mx * mx) <= moved2);
+            if (__builtin_amdgcn_ballot_w64(mv) != 0ull && lane == 0) sred[2] = 1;
+        }
         TRACE_COARSE(1);
         if (!EARLY_TABLES) group_sync<WL>();                 // (EARLY_TABLES: taken ahead of the loads' return)
         TRACE_COARSE(2);
+        // CACHED_B: workgroup-uniform (every thread reads the same word; agent 0 clears it behind the verdict barrier)
+        const bool rebuild = CACHED_B ? (__builtin_amdgcn_readfirstlane(sred[2]) != 0) : true;
         if (FAR && step == 0 && a.far_inm && !uniform && valid) {
 #pragma nounroll
             for (int j = 0; j < N; ++j) far_total += (j != agent && dhat <= sconst[j].x) ? 1 : 0;
         }
-        if (use_bucket) {
+        if (use_bucket && rebuild) {
             if (valid) {
                 atomicOr(&sbt[(agent >> 6) * kCells + bcx], 1ull << (agent & 63));           // [axis][word][cell]:
                 atomicOr(&sbt[(W + (agent >> 6)) * kCells + bcy], 1ull << (agent & 63));     // lanes spread over banks
@@ -891,6 +909,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             int npool = 0;
             const int cxm = (bcx - 1) & (kCells - 1), cxp = (bcx + 1) & (kCells - 1);
             const int cym = (bcy - 1) & (kCells - 1), cyp = (bcy + 1) & (kCells - 1);
+            const float thr_t = CACHED_B ? thr_list : thr;   // CACHED_B: the test below builds the LIST; pass 2 drops listed-but-far pairs
+            if (CACHED_B && !rebuild) {
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) pool[w] = candw[w];
+            } else {
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) {
                 pool[w] = 0ull;
@@ -920,7 +943,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
 #pragma unroll
                 for (int w = 0; w < WMAX; ++w) {
                     const float dx = xi - pf[w].x, dy = yi - pf[w].y;
-                    if (pool[w] != 0ull && fmaf(dy, dy, dx * dx) < thr) first[w] = 1ull << uf[w];
+                    if (pool[w] != 0ull && fmaf(dy, dy, dx * dx) < thr_t) first[w] = 1ull << uf[w];
                     pool[w] &= pool[w] - 1ull;
                 }
             }
@@ -943,8 +966,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                                 for (int u = 0; u < kChunk / 2; ++u) {
                                     const float4 v = pp[u];
                                     const float dx0 = xi - v.x, dy0 = yi - v.y, dx1 = xi - v.z, dy1 = yi - v.w;
-                                    m |= (fmaf(dy0, dy0, dx0 * dx0) < thr ? 1u : 0u) << (2 * u);
-                                    m |= (fmaf(dy1, dy1, dx1 * dx1) < thr ? 1u : 0u) << (2 * u + 1);
+                                    m |= (fmaf(dy0, dy0, dx0 * dx0) < thr_t ? 1u : 0u) << (2 * u);
+                                    m |= (fmaf(dy1, dy1, dx1 * dx1) < thr_t ? 1u : 0u) << (2 * u + 1);
                                 }
                                 if (cnt < kChunk) m &= (1u << cnt) - 1u;
                                 hits |= (unsigned long long)m << (c4 * kChunk);
@@ -958,7 +981,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                             m &= m - 1ull;
                             const float2 pj = spos_env[64 * w + u];
                             const float dx = xi - pj.x, dy = yi - pj.y;
-                            if (fmaf(dy, dy, dx * dx) < thr) hits |= 1ull << u;
+                            if (fmaf(dy, dy, dx * dx) < thr_t) hits |= 1ull << u;
                         }
                     }
 #if defined(DRONESIM_ABLATE_PASS2)
@@ -967,6 +990,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     pool[w] = hits;                          // the verdicts replace the candidates
                 }
             }
+            if (CACHED_B) {                                  // keep the list and where it was taken
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) candw[w] = pool[w];
+                refx = xi; refy = yi;
+            }
+            }   // rebuild
             TRACE_FINE(2);                                   // (-DDRONESIM_TRACE_FINE: candidates tested)
             // pass 2 over the verdicts, ascending agent order.  Workgroup-per-env geometries (ascending-order list):
             // the hot walk defers the general insertion and is written out for the uniform-(Delta, l) case, like kSym64's
@@ -1477,6 +1506,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     accw = make_uint4(w0.x, w0.y, w1.x, w1.y);
                 }
                 *reinterpret_cast<int2 *>(sred + 2 * slot) = make_int2(0, (auto_reset && fin) ? 1 : 0);   // under auto_reset: "re-sample this env"
+                if (CACHED_B) sred[2] = 0;                   // the "moved" flag: every thread has read it (barriers in between)
             } else {                                              // train_problem.py:100 and t_iter, every step
                 accw.x += (unsigned)coll_env; accw.y += 1u;
             }

@@ -1139,18 +1139,20 @@ def formation_xF(N, G):
     return formation_O(N, [G, G])[0].reshape(N, 2).astype(np.float32)
 
 
-def test_rollout_candidate_list_is_bit_transparent(torch):
-    """The fused rollout of N = 64 keeps the far filter's verdicts in registers between steps (list radius
-    reach + skin, refreshed once an agent has moved skin/2); the per-launch step kernel filters every step.
-    Both must agree bit for bit over long trajectories with slow, fast and very fast agents."""
-    N, G, E, T = 64, 28.0, 256, 150
+@pytest.mark.parametrize("N,G,E,T", [(64, 28.0, 256, 150), (256, 256.0, 40, 120), (130, 40.0, 24, 120), (250, 64.0, 6, 80),
+                                       (65, 12.0, 30, 60)])
+def test_rollout_candidate_list_is_bit_transparent(torch, N, G, E, T):
+    """The fused rollouts of N = 64 and of the workgroup-per-env geometry up to 256 agents keep the far filter's verdicts
+    in registers between steps (list radius reach + skin, refreshed once an agent of the env has moved skin/2); the
+    per-launch step kernel filters every step.  Both must agree bit for bit over long trajectories with slow, fast and
+    very fast agents (sparse C5-like envs, dense ones that take the crowded path, ragged last waves)."""
     a = make_env(N, G, 2, 2, np.ones(N), E, seed=77)
     b = make_env(N, G, 2, 2, np.ones(N), E, seed=77)
     g = torch.Generator(device="cuda:0").manual_seed(5)
     act = torch.rand(T, E, N, 2, device="cuda:0", generator=g) * 2 - 1
     act[::7] *= 4.0                                            # bursts: several list refreshes in a row
     act[50:60, ::4] = 0.0                                      # and envs that do not move at all
-    act[100] *= 40.0                                           # teleport-sized jump
+    act[min(100, T - 10)] *= 40.0                              # teleport-sized jump
     out = a.rollout(act)
     for s in range(T):
         res = b.step(act[s])
@@ -1158,7 +1160,8 @@ def test_rollout_candidate_list_is_bit_transparent(torch):
                           ("nbr_idx", b.nbr_idx), ("n_coll", res.n_collisions), ("done", res.finished)):
             assert torch.equal(out[name][s], ref), (name, s)
     assert torch.equal(a.pos, b.pos) and torch.equal(a.t, b.t)
-    assert int(out["n_coll"].sum()) > 0
+    assert G > 100 or int(out["n_coll"].sum()) > 0
+    assert int((out["nbr_idx"][:, :, :, 1:] >= 0).sum()) > 0      # some agent had a real neighbour inside its Delta disk
 
 
 def test_batched_policy_bf16_variant(torch):
