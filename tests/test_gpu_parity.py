@@ -1146,8 +1146,9 @@ def test_rollout_candidate_list_is_bit_transparent(torch, N, G, E, T):
     in registers between steps (list radius reach + skin, refreshed once an agent of the env has moved skin/2); the
     per-launch step kernel filters every step.  Both must agree bit for bit over long trajectories with slow, fast and
     very fast agents (sparse C5-like envs, dense ones that take the crowded path, ragged last waves)."""
-    a = make_env(N, G, 2, 2, np.ones(N), E, seed=77)
-    b = make_env(N, G, 2, 2, np.ones(N), E, seed=77)
+    deltas = np.ones(N) * (1.0 if N == 64 else 0.3)           # Delta < d_hat on every shape: the kernels with the list, not FAR
+    a = make_env(N, G, 2, 2, deltas, E, seed=77)
+    b = make_env(N, G, 2, 2, deltas, E, seed=77)
     g = torch.Generator(device="cuda:0").manual_seed(5)
     act = torch.rand(T, E, N, 2, device="cuda:0", generator=g) * 2 - 1
     act[::7] *= 4.0                                            # bursts: several list refreshes in a row
