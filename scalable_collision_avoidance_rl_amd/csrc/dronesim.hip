@@ -796,6 +796,16 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     g_i32 *p_ncoll = o_ncoll;
     g_u8 *p_done = o_done;
 
+    // Fused rollout: everything loaded ahead of the loop is waited for HERE, once.  Left pending, the compiler's wait
+    // for it sits at its first use INSIDE the loop -- a vmcnt(0) in front of the rewards and a vmcnt(1) at the loop top
+    // that on every later step wait for the step's own output stores and the next action's prefetch instead (gfx950
+    // counts loads and stores in one in-order counter)
+#if !defined(DRONESIM_NO_ROLLOUT_PREWAIT)
+    if (MODE == kRollout && !rand_act)                        // (in-kernel actions: nothing is prefetched; measured +2 % with it)
+        asm volatile("" : : "v"(xi), "v"(yi), "v"(u0.x), "v"(u0.y), "v"(xFx), "v"(xFy), "v"(xLx), "v"(xLy), "v"(dhat), "v"(delta_i),
+                     "v"(li), "v"(tcur), "v"(epi), "v"(accw.x), "v"(accw.y), "v"(accw.z), "v"(accw.w));
+#endif
+    float2 unext = make_float2(0.f, 0.f);                    // fused rollout: the next step's action, in flight
     // @phase integrate
     for (int step = 0; step < nsteps; ++step) {
         const size_t so = (MODE == kRollout) ? (size_t)step * step_agents : 0;   // output offset (agents)
@@ -815,11 +825,29 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             if (valid && a.act_out != nullptr)
                 st_out2(a.act_out + 2 * (so + wga0 + lane), u0.x, u0.y);
         }
+        // fused rollout: the next step's action is prefetched under this step's work.  Requested by EVERY lane (a lane
+        // without an agent repeats lane 0's address; a wave without agents reads the pool's first bytes): under `valid`
+        // the value would be merged into u0 where the masked region ends, i.e. waited for six instructions later --
+        // together with every output store of the previous step (N > 64: 2 of 3.6 us per step at the C5 shard)
+        // (kept in registers of its own until it has arrived: merged into u0 right away, a half of the 8-byte load that
+        // the allocator places elsewhere is copied -- and waited for -- right behind the request)
+        // (the packed geometry keeps the round-2 form, prefetch under `valid` straight into u0: at its 128-register cap
+        // the separate pair is itself copied and waited for at once -- C2 +5 %)
+#if defined(DRONESIM_NO_ROLLOUT_PREWAIT)
+        constexpr bool PREFETCH_SEP = false;
+#else
+        constexpr bool PREFETCH_SEP = MODE == kRollout && GEO != kPacked;
+#endif
+        if (PREFETCH_SEP && !rand_act && step > 0) u0 = unext;
+        const float2 u = u0;
+        if (PREFETCH_SEP && !rand_act && step + 1 < nsteps) {
+            const float2 *nxt = reinterpret_cast<const float2 *>(a.act) + (nval > 0 ? so + step_agents + wga0 : 0);
+            unext = nxt[valid ? lane : 0u];
+        }
+        if (MODE == kRollout && !PREFETCH_SEP && !rand_act && valid && step + 1 < nsteps)
+            u0 = (reinterpret_cast<const float2 *>(a.act) + so + step_agents + wga0)[lane];
         if (valid) {
             if (MODE != kObserve) {
-                const float2 u = u0;
-                if (MODE == kRollout && !rand_act && step + 1 < nsteps)   // prefetch the next step's action under this step's work
-                    u0 = (reinterpret_cast<const float2 *>(a.act) + so + step_agents + wga0)[lane];
                 xi = fmaf(a.dt, u.x, xi);                     // drone_env.py:235
                 yi = fmaf(a.dt, u.y, yi);
                 vxi = u.x; vyi = u.y;                         // drone_env.py:238
@@ -1263,6 +1291,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         float r_env = 0.0f, tr_env = 0.0f;                    // their sums over the env, valid in its agent-0 lane
         int coll_s = 0;                                       // kSym64: the env's collisions / agents outside the goal
         unsigned long long outside_m = 0ull;                  //         disk, wave-uniform (scalar registers)
+#if !defined(DRONESIM_NO_ROLLOUT_PREWAIT)
+        // fused rollout: the next step's action (prefetched at the top of this step) is waited for HERE, ahead of the
+        // step's first output store -- at the loop's end the same wait would also cover the stores just issued
+        if (MODE == kRollout && GEO != kPacked) asm volatile("" : "+v"(unext.x), "+v"(unext.y));
+#endif
         if (valid) {
             TRACE_MARK(3);
             // rewards (:276, :287-288)
