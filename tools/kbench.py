@@ -15,7 +15,7 @@ import torch
 from scalable_collision_avoidance_rl_amd import drones
 
 PRESETS = {"c2": (5, 1024, 5.0, 1.0), "c3": (64, 4096, 28.0, 1.0), "c5": (256, 512, 256.0, 2.5),
-           "c3x8": (64, 32768, 28.0, 1.0), "c2x32": (5, 32768, 5.0, 1.0)}
+           "c3x8": (64, 32768, 28.0, 1.0), "c2x32": (5, 32768, 5.0, 1.0), "c5x8": (256, 4096, 256.0, 2.5)}
 
 
 def run(spec, steps=200, reps=20):

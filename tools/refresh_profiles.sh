@@ -33,6 +33,7 @@ cp $(find $OUT/prof_c3_bench -name '*domain_stats.csv' | head -1) $OUT/${TAG}_c3
 (cd $ROOT && prof rollout python tools/rbench.py c3 c5)
 (cd $ROOT && PB_PREC=f32,bf16x3 prof c5_policy python tools/pbench.py c5)
 (cd $ROOT && prof far_kbench python tools/abtest.py --one c3f,c5f)
+(cd $ROOT && prof c5_kbench python tools/kbench.py c5 c5x8)
 (cd $ROOT && prof fbench python tools/fbench.py)
 (cd $ROOT && prof reset_probe python tools/reset_probe.py c3)
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -43,5 +44,5 @@ done
 (cd $ROOT/tools && python pmc_parse.py $OUT/pmc_$TAG c3 > $OUT/${TAG}_c3_pmc_traffic.json)
 tail -5 $OUT/${TAG}_c3_pmc_traffic.json
 (cd $ROOT && bash tools/sq_counters.sh $TAG c3 > $OUT/${TAG}_sq.log 2>&1)
-(cd $ROOT && $T python tools/kbench.py c3 c2 c5 256x4096:256:2.5 c3x8 > $OUT/${TAG}_kbench.log 2>&1; $T python tools/kbench.py 64x512:28:1.0 64x1024:28:1.0 64x2048:28:1.0 64x4096:28:1.0 64x8192:28:1.0 64x16384:28:1.0 > $OUT/${TAG}_esweep.log 2>&1; $T python tools/probe_floor.py > $OUT/${TAG}_probe_floor.log 2>&1; PB_PREC=f32,bf16x3,f16x2,bf16 $T python tools/pbench.py c3 c5 > $OUT/${TAG}_pbench.log 2>&1; $T python tools/rbench.py c3 c5 > $OUT/${TAG}_rbench.log 2>&1; $T python tools/epibench.py 5 c3 > $OUT/${TAG}_epibench.log 2>&1; $T python tools/reset_probe.py c3 c5 c2 > $OUT/${TAG}_reset_probe.log 2>&1; $T python tools/fbench.py > $OUT/${TAG}_fbench.log 2>&1)
+(cd $ROOT && $T python tools/kbench.py c3 c2 c5 256x4096:256:2.5 c3x8 > $OUT/${TAG}_kbench.log 2>&1; $T python tools/kbench.py 64x512:28:1.0 64x1024:28:1.0 64x2048:28:1.0 64x4096:28:1.0 64x8192:28:1.0 64x16384:28:1.0 > $OUT/${TAG}_esweep.log 2>&1; $T python tools/probe_floor.py > $OUT/${TAG}_probe_floor.log 2>&1; PB_PREC=f32,bf16x3,f16x2,bf16 $T python tools/pbench.py c3 c5 > $OUT/${TAG}_pbench.log 2>&1; $T python tools/rbench.py c3 c5 c5x8 > $OUT/${TAG}_rbench.log 2>&1; $T python tools/epibench.py 5 c3 > $OUT/${TAG}_epibench.log 2>&1; $T python tools/reset_probe.py c3 c5 c2 > $OUT/${TAG}_reset_probe.log 2>&1; $T python tools/fbench.py > $OUT/${TAG}_fbench.log 2>&1)
 cat $OUT/${TAG}_kbench.log
