@@ -394,6 +394,10 @@ constexpr int kBlockStepWaves = DRONESIM_BLOCK_WAVES;
 #if !defined(DRONESIM_BLOCK_WAVES_EPI)
 #define DRONESIM_BLOCK_WAVES_EPI 6
 #endif
+#if !defined(DRONESIM_BLOCK_ROLLOUT_EPI_WAVES)
+#define DRONESIM_BLOCK_ROLLOUT_EPI_WAVES 4   // (3 = no spills, but N = 256 x 4096 envs with in-kernel actions 16.4 against 14.1 us per step)
+#endif
+constexpr int kBlockRolloutEpiWaves = DRONESIM_BLOCK_ROLLOUT_EPI_WAVES;
 constexpr int kBlockStepWavesEpi = DRONESIM_BLOCK_WAVES_EPI;   // (8 makes the episode-layer kernels spill on the hot path)
 
 template <int GEO> struct GeoTraits {
@@ -414,7 +418,7 @@ template <int GEO> struct GeoTraits {
     {
         const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves
                                      : (GEO == kBlock256 && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
-                                     : (GEO == kBlock256 && epi) ? 3 : 4;   // (the block rollout with the episode layer spilled at 128 registers)
+                                     : (GEO == kBlock256 && epi) ? kBlockRolloutEpiWaves : 4;   // (the block rollout with the episode layer spills at 128 registers)
         const int cap = k <= 2 ? 8 : k <= 4 ? 6 : 4;
         return want < cap ? want : cap;
     }
