@@ -582,6 +582,43 @@ def test_rollout_equals_sequential_steps(torch, N, G, E, T, c):
     assert torch.equal(a.z, b.z)
 
 
+@pytest.mark.parametrize("N,G,E,k,c,kind,T,auto", [
+    (128, 38.0, 9, 3, 2, "uniform", 25, True),        # tools/fuzz_rollout.py seed 7 #23: caught a wrong re-observation (round 3)
+    (128, 38.0, 32, 3, 2, "uniform", 49, True), (256, 70.0, 6, 2, 2, "uniform", 40, True), (200, 51.0, 5, 4, 2, "hetero", 30, True),
+    (65, 22.0, 20, 1, 2, "uniform", 40, True), (130, 64.0, 12, 2, 5, "none", 30, True), (64, 22.0, 30, 3, 2, "uniform", 40, True),
+    (250, 118.0, 4, 8, 2, "uniform", 30, False), (24, 12.0, 30, 5, 2, "hetero", 40, True), (300, 81.0, 3, 2, 2, "uniform", 25, True)])
+def test_rollout_with_pool_actions_equals_steps_across_resets(torch, N, G, E, k, c, kind, T, auto):
+    """dronesim_rollout_ex with actions from a pool (prefetched inside the kernel), candidate lists and in-kernel resets
+    against the same steps launched one by one, bit for bit, with episodes ending inside the rollout: the configuration
+    class tools/fuzz_rollout.py draws from (k = 1 .. 8, all geometries, uniform / heterogeneous / default Delta)."""
+    from scalable_collision_avoidance_rl_amd import drones, formation_O
+    rng = np.random.default_rng(N + 7 * k)
+    d_hat = formation_O(N, [G, G])[1]
+    deltas = (np.ones(N) * 0.47 * d_hat.min() if kind == "uniform" else rng.uniform(0.1, 1.3, N) * d_hat.min() if kind == "hetero"
+              else None)
+    kw = dict(auto_reset=True) if auto else {}
+    mk = lambda: drones(N, 0, [G, G], "O", k_closest=k, deltas=deltas, simplify_zstate=(c == 2), n_envs=E, batched=True,
+                        device="cuda:0", seed=321, **kw)
+    a, b = mk(), mk()
+    pos0 = (G / 2 + (rng.random((E, N, 2)) - 0.5) * 0.6 * G).astype(np.float32)
+    t0 = rng.integers(150, 199, E).astype(np.int32) if auto else np.zeros(E, np.int32)
+    t0[-1] = 199 - T // 2                                       # an episode ends in the middle of the rollout
+    a.set_state(pos0, None, t0); b.set_state(pos0, None, t0)
+    g = torch.Generator(device="cuda:0").manual_seed(N)
+    act = torch.rand(T, E, N, 2, device="cuda:0", generator=g) * 2 - 1
+    act[::5] *= 3.0
+    act[T // 3:T // 3 + 6, ::3] = 0.0
+    act[T - 5] *= 30.0
+    out = a.rollout(act)
+    for s in range(T):
+        res = b.step(act[s])
+        for name, ref in (("reward", res.rewards), ("true_reward", res.true_rewards), ("z", res.z_states),
+                          ("nbr_idx", b.nbr_idx), ("n_coll", res.n_collisions), ("done", res.finished)):
+            assert torch.equal(out[name][s], ref), (name, s)
+    assert torch.equal(a.pos, b.pos) and torch.equal(a.t, b.t)
+    assert not auto or bool(out["done"].any())
+
+
 def test_step_is_deterministic_and_full_episode_runs(torch):
     """Run-to-run bit equality (race-freedom evidence) and a 200-step batched episode at C3 size."""
     N, G, E = 64, 28.0, 4096
