@@ -395,12 +395,11 @@ constexpr int kBlockStepWaves = DRONESIM_BLOCK_WAVES;
 #define DRONESIM_BLOCK_WAVES_EPI 6
 #endif
 #if !defined(DRONESIM_BLOCK_ROLLOUT_EPI_WAVES)
-#define DRONESIM_BLOCK_ROLLOUT_EPI_WAVES 3
-// 3 = a 168-register budget.  At 4 (128 registers, spills) N = 256 x 4096 envs with in-kernel actions run 14.1 instead of
-// 16.4 us per step -- but that build of the k = 3 kernel (candidate list + separate prefetch registers) marked partners
-// outside their Delta disk as neighbours in the re-observation after an in-kernel reset (tools/fuzz_rollout.py, seeds 7 / 9:
-// N = 128, k = 3, auto_reset; the same source is right at 168 registers, without the list, or without the prefetch
-// registers; no source-level cause found -- DESIGN.md 7).  Correctness first: the budget that passes the fuzz.
+#define DRONESIM_BLOCK_ROLLOUT_EPI_WAVES 4
+// 4 = the 128-register budget (small spills): N = 256 x 4096 envs with in-kernel actions 14.1 us per step against 16.4 at
+// 3 (168 registers, no spills).  (The k = 3 kernel of this family was the one hipcc mis-lowered while the re-observation
+// after an in-kernel reset still walked one exec-masked loop per word -- see the cold path; tools/fuzz_rollout.py and
+// test_rollout_with_pool_actions_equals_steps_across_resets guard it.)
 #endif
 constexpr int kBlockRolloutEpiWaves = DRONESIM_BLOCK_ROLLOUT_EPI_WAVES;
 constexpr int kBlockStepWavesEpi = DRONESIM_BLOCK_WAVES_EPI;   // (8 makes the episode-layer kernels spill on the hot path)
@@ -1705,14 +1704,28 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                                 bits[w] |= (hit && 64 * w + u != agent) ? (1ull << u) : 0ull;
                             }
                         }
+                        // ONE loop over the bits of all words, every lane taking its own lowest partner per trip (ascending
+                        // order, like every other path).  Not one loop per word: hipcc (ROCm 7.2) lowered the four
+                        // exec-masked per-word loops of the k = 3 rollout of the episode layer, at its 128-register budget,
+                        // with the copy that merges `in_range` behind the LAST word's loop placed ahead of the exec
+                        // restore -- lanes without partners in that word (all of them at N = 128) kept a stale temporary
+                        // there and the re-observed rows marked partners outside their Delta disk as neighbours
+                        // (tools/fuzz_rollout.py seeds 7 / 9).  A single loop has a single merge point, the shape
+                        // of the hot walk.
+                        unsigned long long left = 0ull;
 #pragma unroll
-                        for (int w = 0; w < WMAX; ++w) {
-                            unsigned long long m = bits[w];
-                            while (m) {                           // ascending order, like every other path
-                                const int u = __builtin_ctzll(m);
-                                m &= m - 1ull;
-                                visit(64 * w + u, NoDefer{}, UniRuntime{});
-                            }
+                        for (int w = 0; w < WMAX; ++w) left |= bits[w];
+                        while (left != 0ull) {
+                            unsigned long long hs = bits[WMAX - 1];
+                            int ws = WMAX - 1;
+#pragma unroll
+                            for (int w = WMAX - 2; w >= 0; --w) { if (bits[w] != 0ull) { hs = bits[w]; ws = w; } }
+                            const int u = __builtin_ctzll(hs);
+                            hs &= hs - 1ull;
+                            left = 0ull;
+#pragma unroll
+                            for (int w = 0; w < WMAX; ++w) { if (w == ws) bits[w] = hs; left |= bits[w]; }
+                            visit(64 * ws + u, NoDefer{}, UniRuntime{});
                         }
                     } else {
 #pragma nounroll
