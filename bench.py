@@ -29,6 +29,7 @@ them (c2, the c5 shard, the c5 shard with the float32 Gaussian policy in the loo
 appends them as `other_workloads`.
 
     python bench.py --gpus 1 --steps 2000 --warmup 200
+    python bench.py --gpus 8 --steps 2000 --warmup 200        # starts its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 2000 --warmup 200
 """
@@ -248,6 +249,39 @@ def rccl_probe():
     return None
 
 
+def visible_gpus():
+    """Number of GPUs this process could use, WITHOUT creating a HIP context in the parent of the ranks."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                           capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1])
+    except (subprocess.SubprocessError, OSError, ValueError, IndexError):
+        return 0
+
+
+def spawn_ranks(n):
+    """Re-run this command as `n` ranks of one node through torch.distributed.run (one process per GPU, RCCL over xGMI
+    under backend "nccl"; rendezvous on 127.0.0.1 and a free port).  Returns the launcher's exit code.  With fewer than
+    `n` visible GPUs the run is REFUSED (exit code 2) unless BENCH_ONE_DEVICE=1 asks for all ranks on device 0 (the
+    launcher tests on a one-GPU box, backend gloo)."""
+    import socket
+    import subprocess
+    if not os.environ.get("BENCH_ONE_DEVICE"):
+        have = visible_gpus()
+        if have < n:
+            print(f"bench.py: --gpus {n} needs {n} GPUs, {have} visible: refusing to run (a one-rank run must not be "
+                  f"reported as a {n}-GPU figure; BENCH_ONE_DEVICE=1 BENCH_BACKEND=gloo puts all ranks on device 0 "
+                  "for launcher tests)", file=sys.stderr)
+            return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -275,6 +309,11 @@ def main():
     ap.add_argument("--no-rccl-probe", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher around it (how the driver's scaling run may call it): start the N
+        # ranks ourselves, one process per GPU, and let rank 0 print the line.  Never a silent one-rank run.
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     from scalable_collision_avoidance_rl_amd import drones, max_time_steps
@@ -288,6 +327,10 @@ def main():
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if os.environ.get("BENCH_ONE_DEVICE"):
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU (local rank {local_rank}, {torch.cuda.device_count()} visible device(s))",
+              file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -295,7 +338,10 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)", file=sys.stderr)
+        sys.exit(2)
     cdev = dev if backend == "nccl" else "cpu"           # where small control tensors of the collectives live
 
     N, e_gpu, G, delta, label = WORKLOADS[args.workload]
@@ -557,6 +603,8 @@ def main():
                                         % ("RCCL (backend nccl)" if backend == "nccl" else backend, world)) if world > 1 else
                                        "none: world_size 1, the reduced vectors are already everywhere (see rccl_probe)",
                          "real_collective_ran": bool(world > 1),
+                         "backend": backend if world > 1 else None,
+                         "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else 0),
                          "collective_latency_us": allgather_us},
             "launch_check": launch_check,
             "episode_end_stats": summary,

@@ -174,11 +174,14 @@ typedef struct DroneEpisodeCtl {
      * the last transition (utils.py:244-249) before it resets (train_problem.py:132).  With auto_reset the launch that
      * ends an episode overwrites z / nbr_idx / pos with the NEW episode's first observation; when these pointers are
      * given, the finished env's terminal rows are kept here instead of being lost: written ONLY for envs whose `done`
-     * fired in this launch (rows of other envs are left untouched), same layouts as z / nbr_idx / pos
-     * ([T][...] like z in the fused rollouts).                                                                  */
-    float *z_final;             /* [E][N][k+1][c]                                                    */
-    int32_t *nbr_final;         /* [E][N][k+1]                                                       */
-    float *pos_final;           /* [E][N][2]                                                         */
+     * fired in this launch (rows of other envs are left untouched), same layouts as z / nbr_idx / pos.
+     * SIZE: dronesim_step_ex writes rows [e][i]; the fused rollouts (dronesim_rollout_ex / _rollout_random) write
+     * the rows of an env that finishes at step s at [s][e][i], exactly like their z output: there all three buffers
+     * must hold T x E x N rows.  Passing [E]-sized buffers to a rollout of T > 1 steps is a caller error the library
+     * cannot detect (plain pointers).                                                                           */
+    float *z_final;             /* step: [E][N][k+1][c];  rollout: [T][E][N][k+1][c]                 */
+    int32_t *nbr_final;         /* step: [E][N][k+1];     rollout: [T][E][N][k+1]                    */
+    float *pos_final;           /* step: [E][N][2];       rollout: [T][E][N][2]                      */
 } DroneEpisodeCtl;
 
 /* dronesim_step / dronesim_rollout with episode bookkeeping and optional in-kernel auto-reset.  ctl == NULL
@@ -267,7 +270,8 @@ typedef struct DroneMlp {
                              * 1: w2 = float32 matrix-core fragments [N][ceil(h2/32)][ceil(h1/16)][2][64][4] with
                              *    w2[a][c][s][q][l][j] = W2_a[16 s + 8 (l >> 5) + 4 q + j][32 c + (l & 31)], zero beyond
                              *    h1 / h2 -- packed once per weight update, read with 16-byte coalesced loads (the fast
-                             *    path; what the host class BatchedMLP passes).  Same arithmetic, float32 throughout.  */
+                             *    path; what the host class BatchedMLP passes).  Same arithmetic, float32 throughout.
+                             *    The packed array must be 16-byte aligned (EINVAL otherwise).                          */
     const float *w1, *b1, *w2, *b2, *w3, *b3;
 } DroneMlp;
 int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,

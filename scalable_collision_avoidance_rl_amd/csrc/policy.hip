@@ -1346,6 +1346,8 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     if (!m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3)
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
     if (m->w2_layout != 0 && m->w2_layout != 1) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: w2_layout must be 0 or 1");
+    if (m->w2_layout == 1 && (reinterpret_cast<uintptr_t>(m->w2) & 15u) != 0)     // read with 16-byte vector loads
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: fragment-packed w2 (w2_layout = 1) must be 16-byte aligned");
     if (E == 0) return DRONESIM_OK;
     MArgs a{};
 #if defined(DRONESIM_TRACE)

@@ -135,6 +135,8 @@ class drones:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError(f"device must be a ROCm GPU, got {self.device}")
+        if self.device.index is None:                 # "cuda" -> "cuda:<current>": tensors always carry an index
+            self.device = torch.device("cuda", torch.cuda.current_device())
 
         self.n_agents = int(n_agents)
         self.grid = grid
@@ -319,6 +321,18 @@ class drones:
         views["_result"] = self._result
         self._bound_home = home
 
+    def _rebind_home(self):
+        """After step(into=(storage, t)) the observation attributes are views of a storage slot.  Everything that
+        writes through them outside step() (reset, set_state, load_state, rollout) first returns to the env's own
+        buffers, carrying the current observation over, so that stored experience is never clobbered."""
+        if self._bound_home:
+            return
+        cur = dict(z=self.z, nbr_idx=self.nbr_idx, reward=self.reward, true_reward=self.true_reward, n_coll=self.n_coll,
+                   done=self.done)
+        self._bind(self._home, home=True)
+        for name, src in cur.items():
+            self._home[name].copy_(src)
+
     @property
     def _use_ctl(self):
         return self.track_episodes or self.auto_reset
@@ -340,6 +354,7 @@ class drones:
 
         ``mask`` (bool/uint8 ``[E]`` device tensor, batched mode) resets only the flagged envs."""
         torch = self._torch
+        self._rebind_home()
         m = None
         if mask is not None:
             m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
@@ -463,7 +478,8 @@ class drones:
         Returns a dict of ``[T, ...]`` tensors with every per-step output of step(); ``with_pre=True`` adds
         ``z_pre`` / ``nbr_idx_pre``, the observation each action was based on (what the reference stores as
         ``z_state`` / ``Ni`` in its experience tuples, utils.py:236-249).  With ``auto_reset`` the rollout runs
-        across episode ends (see step())."""
+        across episode ends (see step()); with ``keep_final_obs`` the dict also holds ``z_final`` / ``nbr_final`` /
+        ``pos_final`` ``[T, ...]``: at ``[s]``, the terminal observation / state of the envs whose ``done[s]`` fired."""
         torch = self._torch
         E, N, K1, c = self.n_envs, self.n_agents, self.k_closest + 1, self.c
         random_actions = _random is not None
@@ -483,18 +499,26 @@ class drones:
                    done=torch.empty(T, E, dtype=torch.uint8, device=self.device))
         if not self.batched:
             self._push_host_state()
+        self._rebind_home()
         p = self._params()
         z0, nb0 = (self.z.clone(), self.nbr_idx.clone()) if with_pre else (None, None)
+        # the rollout kernels address the terminal-observation buffers per STEP ([T][E][N]... like z): a ctl of this
+        # call with [T, ...] buffers (returned in `out`), never the [E, ...] home buffers of step()
+        if self.keep_final_obs:
+            out["z_final"] = torch.zeros(T, E, N, K1 * c, **f32)
+            out["nbr_final"] = torch.full((T, E, N, K1), -1, dtype=torch.int32, device=self.device)
+            out["pos_final"] = torch.zeros(T, E, N, 2, **f32)
+        ctl = self._make_ctl(out.get("z_final"), out.get("nbr_final"), out.get("pos_final"))
         with torch.cuda.device(self.device):
             if random_actions:
                 rc = self._lib.dronesim_rollout_random(
-                    C.byref(p), C.byref(self._ctl()), self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
+                    C.byref(p), C.byref(ctl), self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
                     None if act is None else act.data_ptr(), out["reward"].data_ptr(), out["true_reward"].data_ptr(),
                     out["z"].data_ptr(), out["nbr_idx"].data_ptr(), out["n_coll"].data_ptr(),
                     out["done"].data_ptr(), E, T, self._stream())
             else:
                 rc = self._lib.dronesim_rollout_ex(
-                    C.byref(p), C.byref(self._ctl()) if self._use_ctl else None, self.pos.data_ptr(),
+                    C.byref(p), C.byref(ctl) if self._use_ctl else None, self.pos.data_ptr(),
                     self.vel.data_ptr(), self.t.data_ptr(), act.data_ptr(), out["reward"].data_ptr(),
                     out["true_reward"].data_ptr(), out["z"].data_ptr(), out["nbr_idx"].data_ptr(),
                     out["n_coll"].data_ptr(), out["done"].data_ptr(), E, T, self._stream())
@@ -508,6 +532,9 @@ class drones:
             self.z.copy_(out["z"][-1]); self.nbr_idx.copy_(out["nbr_idx"][-1])
             self.reward.copy_(out["reward"][-1]); self.true_reward.copy_(out["true_reward"][-1])
             self.n_coll.copy_(out["n_coll"][-1]); self.done.copy_(out["done"][-1])
+            if self.keep_final_obs:                       # rows of the envs whose `finished` the LAST step raised, as after step()
+                self.z_final.copy_(out["z_final"][-1]); self.nbr_final.copy_(out["nbr_final"][-1])
+                self.pos_final.copy_(out["pos_final"][-1])
         if not self.batched:
             self.internal_t += T
             self._sync_host_views()
@@ -550,6 +577,7 @@ class drones:
     def set_state(self, pos, vel=None, t=None):
         """Inject a state (parity tests, checkpoints) and refresh the observation (rewards() path)."""
         torch = self._torch
+        self._rebind_home()
         E, N = self.n_envs, self.n_agents
         self.pos.copy_(torch.as_tensor(np.asarray(pos, np.float32) if not torch.is_tensor(pos) else pos,
                                        dtype=torch.float32).reshape(E, N, 2))
@@ -614,8 +642,8 @@ class drones:
         if self.episode_acc is None:
             raise RuntimeError("construct the env with track_episodes=True (or auto_reset=True)")
         dst = self._episode_totals if out is None else out
-        if out is not None and not (out.dtype == self._torch.float64 and out.numel() == 8 and out.device == self.device
-                                    and out.is_contiguous()):
+        if out is not None and not (out.dtype == self._torch.float64 and out.numel() == 8 and out.is_contiguous()
+                                    and out.device.type == "cuda" and out.device.index == self.device.index):
             raise ValueError("out must be a contiguous float64 [8] tensor on the env's device")
         with self._torch.cuda.device(self.device):
             rc = self._lib.dronesim_episode_reduce(self.episode_acc.data_ptr(), self.n_envs,

@@ -175,7 +175,9 @@ class BatchedMLP:
         needs every weight, input and hidden activation below 65504 in magnitude; ``"bf16"`` runs weights and
         activations in plain bfloat16 with float32 accumulation (~1e-2 relative agreement, fastest).
         ``pack_w2`` (f32 only): hand layer 2's weights to the kernel as matrix-core fragments (`pack_f32_fragments`,
-        the fast path); False keeps the [N, h1, h2] array of the plain C ABI (`DroneMlp.w2_layout = 0`)."""
+        the fast path); False keeps the [N, h1, h2] array of the plain C ABI (`DroneMlp.w2_layout = 0`).
+        NOTE: the packed images are SNAPSHOTS of the weights: after an in-place update of ``w1 .. b3`` call
+        `refresh_weights()` (re-packs into the same device buffers)."""
         import torch
         from . import _native
         self._torch, self._native = torch, _native
@@ -183,6 +185,8 @@ class BatchedMLP:
         if not torch.cuda.is_available():
             raise RuntimeError("BatchedMLP needs a ROCm GPU (MI355X); there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:       # "cuda" -> "cuda:<current>": tensors carry an index
+            self.device = torch.device("cuda", torch.cuda.current_device())
         f = lambda t: torch.as_tensor(t, dtype=torch.float32).to(self.device).contiguous()
         self.w1, self.b1, self.w2, self.b2, self.w3, self.b3 = (f(t) for t in (w1, b1, w2, b2, w3, b3))
         self.n_agents, self.d_in, self.h1 = self.w1.shape
@@ -228,6 +232,29 @@ class BatchedMLP:
         elif precision != "f32":
             raise ValueError("precision must be 'f32', 'f16x2', 'bf16x3' or 'bf16'")
 
+    def refresh_weights(self, w1=None, b1=None, w2=None, b2=None, w3=None, b3=None):
+        """Call after every weight update.  The kernels read PACKED images of the weights (`_w2p` for f32 layer 2;
+        `_w1p/_w2p/_w3p` for the 16-bit paths) that are snapshots taken when the object was built: an in-place update
+        of ``self.w2`` alone (optimizer step) would otherwise leave the kernel on a mix of new and stale weights.
+        Optional arguments are copied into the live tensors first; every packed image is then re-made IN PLACE (same
+        device addresses), so a captured hipGraph that holds them stays valid."""
+        for name, val in (("w1", w1), ("b1", b1), ("w2", w2), ("b2", b2), ("w3", w3), ("b3", b3)):
+            if val is not None:
+                getattr(self, name).copy_(self._torch.as_tensor(val, dtype=self._torch.float32))
+        if self.precision == "f32":
+            if getattr(self, "_w2p", None) is not None:
+                self._w2p.copy_(pack_f32_fragments(self.w2))
+        elif self.precision == "bf16":
+            nc1, nc2 = (self.h1 + 31) // 32, (self.h2 + 31) // 32
+            self._w1p.copy_(pack_bf16_fragments(self.w1, 1, nc1))
+            self._w2p.copy_(pack_bf16_fragments(self.w2, 2 * nc1, nc2))
+            self._w3p.copy_(pack_bf16_fragments(self.w3, 2 * nc2, 1, k_order="accumulator"))
+        else:
+            stages = int(self._lib.dronesim_mlp_bf16x3_stages(self.h1, self.h2))
+            self._w1p.copy_(pack_split_streams(self.w1, self.w2, self.w3, stages, self.precision))
+
+    load_weights = refresh_weights
+
     # ------------------------------------------------------------------ constructors
     @classmethod
     def from_discrete_softmax(cls, modules, **kw):
@@ -257,7 +284,8 @@ class BatchedMLP:
     def _given(self, t, shape, dtype, what):
         """A caller-provided output tensor (e.g. a slot of a `RolloutStorage`): the kernel writes straight into it."""
         torch = self._torch
-        if not (torch.is_tensor(t) and t.device == self.device and t.dtype == dtype and t.is_contiguous()
+        if not (torch.is_tensor(t) and t.device.type == self.device.type and t.device.index == self.device.index
+                and t.dtype == dtype and t.is_contiguous()
                 and t.numel() == int(torch.Size(shape).numel())):
             raise ValueError(f"{what} must be a contiguous {dtype} tensor of {tuple(shape)} elements on {self.device}")
         return t

@@ -84,6 +84,37 @@ def test_bench_py_runs_with_two_ranks_on_one_device():
     assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["step_kernel_ms"] > 0 and r["envs"] == 512 for r in out["per_rank"])
 
 
+def test_bench_py_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with NO launcher and NO WORLD_SIZE in the environment (how the driver's scaling run
+    may call it): bench.py re-runs itself as 2 ranks, and the line is a 2-rank line -- never a silent one-rank run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs-per-gpu", "512",
+                        "--min-seconds", "0.05", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["n_envs_total"] == 1024
+    assert out["exchange"]["real_collective_ran"] is True and out["exchange"]["backend"] == "gloo"
+    assert out["exchange"]["rccl_ranks"] == 0                  # gloo here; = world size under backend nccl
+    assert out["exchange"]["collective_latency_us"] > 0
+    assert out["launch_check"]["ok"] is True
+    assert [q["rank"] for q in out["per_rank"]] == [0, 1]
+
+
+def test_bench_py_refuses_more_gpus_than_the_box_has():
+    """--gpus N beyond the visible devices (and no BENCH_ONE_DEVICE): non-zero exit and a message, no JSON line."""
+    import torch
+    n = torch.cuda.device_count() + 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "5", "--warmup", "1"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "refusing" in r.stderr and not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
 def test_bench_py_strong_scaling_splits_one_job():
     """--scaling strong: the workload's 8-GPU job (8 x envs-per-gpu) is ONE job split over the ranks that run."""
     r = _launch(2, "bench.py", ["--gpus", 2, "--steps", 20, "--warmup", 2, "--envs-per-gpu", 64, "--min-seconds", 0.05,

@@ -237,3 +237,41 @@ def test_bf16_fragment_packing_layouts():
             assert frag[a, c, s, l, j] == want, (order, a, c, s, l, j)
         # every weight appears exactly once
         assert np.isclose(np.abs(frag).sum(), float(w.abs().sum()))
+
+
+def test_no_step_kernel_spills():
+    """Registers / scratch of every instantiation of the BUILT library (tools/kernel_resources.py reads the gfx950 code
+    objects): the single-step and observe kernels of every k <= 7 -- the BASELINE configs are k = 2 -- use no scratch
+    at all (a spill on the hot path is a silent 2x; a register-budget change must not introduce one), the two k = 8
+    instantiations that touch scratch stay within a few dwords, and the headline kernels fit their occupancy targets."""
+    import shutil
+    from tools import kernel_resources as KR
+    if not os.path.exists(KR.READELF) and not shutil.which(KR.READELF):
+        pytest.skip("llvm-readelf not available")
+    lib = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "libdronesim.so")
+    rows = [r for r in KR.resources(lib) if r[1] is not None]
+    assert len(rows) >= 200                                   # 8 k x geometries x modes x episode layer
+    step = [r for r in rows if r[1]["mode"] in (0, 1)]
+    spilled = [(r[0], r[4]) for r in step if r[4] != 0]
+    assert all(r[1]["k"] == 8 and r[4] <= 32 for r in step if r[4] != 0), spilled
+    assert not [s for s in spilled if "K=8" not in s[0]], spilled
+    by = {(r[1]["k"], r[1]["far"], r[1]["mode"], r[1]["geo"], r[1]["epi"]): r for r in rows}
+    # C3's graded kernel (kSym64 step, episode layer) and its plain form: 8 waves per SIMD = at most 64 VGPRs
+    assert by[(2, 0, 0, 1, 1)][2] <= 64 and by[(2, 0, 0, 1, 0)][2] <= 64
+    # C5's kernels (workgroup-per-env, N <= 256): plain 8 waves per SIMD, episode layer 6 (<= 80 VGPRs)
+    assert by[(2, 0, 0, 2, 0)][2] <= 64 and by[(2, 0, 0, 2, 1)][2] <= 80
+
+
+def test_bench_refuses_a_multi_gpu_run_it_cannot_start():
+    """`python bench.py --gpus N` with fewer than N visible GPUs (none in the build container) exits non-zero with a
+    message instead of printing a one-rank line."""
+    import subprocess
+    import sys
+    import torch
+    n = torch.cuda.device_count() + 2
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "3"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    assert not any(l.startswith("{") for l in r.stdout.splitlines())

@@ -31,12 +31,10 @@ def code_objects(blob):
         pos = q
 
 
-def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    path = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-                                             "scalable_collision_avoidance_rl_amd", "libdronesim.so")
-    scratch_only = "--scratch-only" in sys.argv
+def resources(path):
+    """[(short name, dict(k, far, mode, geo, epi) or None, vgpr, sgpr, scratch bytes, static LDS bytes)] of every kernel."""
     blob = open(path, "rb").read()
+    rows = []
     for triple, co in code_objects(blob):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(co); f.flush()
@@ -46,10 +44,22 @@ def main():
             name = g("name")
             m = re.search(r"drone_kernelILi(\d)ELb(\d)ELi(\d)ELi(\d)ELb(\d)", name)
             short = ("drone_kernel<K=%s,FAR=%s,MODE=%s,GEO=%s,EPI=%s>" % m.groups()) if m else name[:60]
-            if scratch_only and g("private_segment_fixed_size") == "0":
-                continue
-            print(f"{short:48s} vgpr {g('vgpr_count'):>4s} sgpr {g('sgpr_count'):>4s} scratch {g('private_segment_fixed_size'):>5s}"
-                  f" static-lds {g('group_segment_fixed_size'):>6s}")
+            inst = dict(zip(("k", "far", "mode", "geo", "epi"), map(int, m.groups()))) if m else None
+            num = lambda k: int(g(k)) if g(k).isdigit() else -1
+            rows.append((short, inst, num("vgpr_count"), num("sgpr_count"), num("private_segment_fixed_size"),
+                         num("group_segment_fixed_size")))
+    return rows
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    path = args[0] if args else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                             "scalable_collision_avoidance_rl_amd", "libdronesim.so")
+    scratch_only = "--scratch-only" in sys.argv
+    for short, _, vgpr, sgpr, scratch, lds in resources(path):
+        if scratch_only and scratch == 0:
+            continue
+        print(f"{short:48s} vgpr {vgpr:>4d} sgpr {sgpr:>4d} scratch {scratch:>5d} static-lds {lds:>6d}")
 
 
 if __name__ == "__main__":
