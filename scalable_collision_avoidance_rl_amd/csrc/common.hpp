@@ -1,5 +1,18 @@
 // Internal helpers shared by the translation units of libdronesim.so (not part of the C ABI).
 #pragma once
+
+// The only build switches of the product source: developer trace builds (per-wave phase stamps; tools/trace_*.py),
+//   make -C csrc -j8 EXTRA=-DDRONESIM_TRACE OUT=../../build/libdronesim_trace.so OBJDIR=../../build/obj_trace
+#if defined(DRONESIM_TRACE)
+constexpr bool kTrace = true;
+#else
+constexpr bool kTrace = false;
+#endif
+#if defined(DRONESIM_TRACE_FINE)
+constexpr bool kTraceFine = true;
+#else
+constexpr bool kTraceFine = false;
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

@@ -35,19 +35,12 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifndef POLICY_F32_ROWS
-#define POLICY_F32_ROWS 32
-#endif
-constexpr int kRows = POLICY_F32_ROWS;   // env rows per workgroup (32-row tiles x 4 feature waves each)
+constexpr int kRows = 32;                // env rows per workgroup (32-row tiles x 4 feature waves each)
 constexpr int kThreadsF = kRows * 8;
 constexpr int kMaxOut = 32;
 
-#if defined(DRONESIM_TRACE)
-long long *g_policy_trace = nullptr;     // developer builds only: [workgroups][4 waves][8] timestamps
-#define PT(k) do { if (a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define PT(k) do { } while (0)
-#endif
+long long *g_policy_trace = nullptr;     // developer trace builds (kTrace, common.hpp) only: [workgroups][4 waves][8] timestamps
+#define PT(k) do { if (kTrace && a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 struct FinishArgs {
     int N, nout, out_kind, sample_kind;
@@ -59,12 +52,10 @@ struct FinishArgs {
 };
 
 struct MArgs {
-#if defined(DRONESIM_TRACE)
-    long long *trace;
-#endif
     int E, N, d_in, h1, h2, nout;
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     FinishArgs fin;
+    long long *trace;                    // developer trace builds only (NULL otherwise)
 };
 
 // LDS row stride (floats) of the h1 tile for the packed layer 2: whole 32-column chunks (the k padding is written as
@@ -255,9 +246,7 @@ __device__ __forceinline__ void tile_gemm(f32x16 &acc, const float *A, int lda, 
 // (8.4k ticks waiting for W1 / b1 / x, 13.7k for ~200 instructions: while the OTHER workgroup's wave on the SIMD streams
 // matrix instructions, this one gets about one issue slot per matrix instruction); raising the issue priority of the
 // waves outside their layer-2 loop (s_setprio 2 / 3) costs 2.4 % instead of helping.  Matrix pipe busy 70 % (54 %).
-#ifndef POLICY_SETS
 #define POLICY_SETS 2         // register sets of the pipeline (see tile_gemm_packed)
-#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct FragSet { f32x4 a0, a1, b0, b1; };
 
@@ -360,10 +349,10 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
                 bias[i] = c0 + col < a.h1 ? b1[c0 + col] : 0.0f;
             }
         }
-#if defined(DRONESIM_TRACE)
-        __builtin_amdgcn_s_waitcnt(0x0070);                      // trace builds: stamp 7 = layer 1's operands have arrived
-        PT(7);
-#endif
+        if (kTrace) {
+            __builtin_amdgcn_s_waitcnt(0x0070);                  // trace builds: stamp 7 = layer 1's operands have arrived
+            PT(7);
+        }
 #pragma unroll
         for (int i = 0; i < kL1; ++i) {
             const int c0 = cw * 32 + 128 * i;
@@ -423,13 +412,7 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     // ... when exactly ONE chunk is left over (13 chunks at h = 400: measured -5.5 % at the C5 shard, -4.3 % at C3); with two
     // or three leftover chunks (h = 300, h = 200) the two barriers and the serial finish per chunk cost more than the
     // balance gains (+1.5 % / +19 %), so those deal their chunks whole as before
-#if defined(POLICY_NO_KSPLIT)
-    const int nch_even = nch;
-#elif defined(POLICY_KSPLIT_ALL)
-    const int nch_even = nch & ~3;
-#else
     const int nch_even = (nch & 3) == 1 ? (nch & ~3) : nch;
-#endif
     // ONE loop over both kinds of trips (one inlined copy of each GEMM: a second copy of the layer-2 loop took the kernel
     // from 244 to 272 registers, i.e. from two workgroups per CU to one): first the whole rounds, then the leftover chunks
     const int rounds = (nch_even + 3) >> 2;                      // (whole dealing: the last round may be ragged)
@@ -530,13 +513,11 @@ constexpr int kRowsB = 64, kTiles = 2;   // 64 env rows (2 row tiles) per workgr
 constexpr int kLdx = 24;                 // bf16 per row of the x tile
 
 struct MArgsB {
-#if defined(DRONESIM_TRACE)
-    long long *trace;
-#endif
     int E, N, d_in, h1, h2, nc1, nc2, ks1;
     const float *x, *b1, *b2, *b3;
     const bf16x8 *w1p, *w2p, *w3p;       // [agent][chunk][k-step][64 lanes] fragments
     FinishArgs fin;
+    long long *trace;                    // developer trace builds only (NULL otherwise)
 };
 
 // relu(acc + bias) of one 32-feature chunk -> bf16 rows [row][feature].  `bias` points at the chunk's 32 biases
@@ -781,10 +762,8 @@ struct MArgsX {
     const float *x, *b1, *b2, *b3;
     const char *ws;                // the per-(agent, wave) fragment streams
     int stages;                    // stages per stream (padded)
-#if defined(DRONESIM_TRACE)
-    long long *trace;              // developer builds only
-#endif
     FinishArgs fin;
+    long long *trace;              // developer trace builds only (NULL otherwise)
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -866,15 +845,7 @@ struct SplitJob {
     __device__ __forceinline__ void all() { pair<0>(); pair<1>(); pair<2>(); pair<3>(); }
 };
 struct NoJob { template <int SLOT> __device__ __forceinline__ void slot() {} };
-#ifdef DRONESIM_ABL_X3_NOSPLIT
-template <class S, int HALF, int TILES> struct NoSplitJob {
-    __device__ __forceinline__ NoSplitJob(const f32x16 &s, Parts<S::kParts> &d) { d.p[0][0] += (unsigned)s[8 * HALF]; }
-    template <int SLOT> __device__ __forceinline__ void slot() {}
-};
-#define SplitJobInStage NoSplitJob
-#else
 #define SplitJobInStage SplitJob
-#endif
 
 // LDS reads the compiler must NOT see: hipcc orders every LDS read it can see behind ALL pending global_load_lds of
 // the wave (s_waitcnt vmcnt(0)), which would drain the weight ring; the bytes read this way (biases, the x operand)
@@ -907,11 +878,7 @@ template <int P> __device__ __forceinline__ Parts<P> parts_from_lds(const char *
 }
 
 #define X3_PIN() __builtin_amdgcn_sched_barrier(0)
-#ifdef DRONESIM_ABL_X3_NOREAD
-#define X3_RING_READ(dst, p) (void)(p)
-#else
 #define X3_RING_READ(dst, p) dst = *reinterpret_cast<const u32x4 *>(p)
-#endif
 
 template <class S, int TILES>
 __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(const float *x, int E, int N, int d_in, const MArgsX rest)
@@ -929,12 +896,10 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
     const int e0 = row_block * kRowsX;
     const int NC1 = a.nc1;
     const int nb = (a.nc1 + a.nc2) * 32;
-#ifdef DRONESIM_TRACE
-    if (a.trace && lane == 0) {                                    // shader clock and the 100 MHz clock at entry
+    if (kTrace && a.trace && lane == 0) {                          // shader clock and the 100 MHz clock at entry
         a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 0] = __builtin_amdgcn_s_memtime();
         a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
     }
-#endif
     float *sbias = reinterpret_cast<float *>(smem);                // b1 | b2 (zero padded to chunks) | b3 (32)
     char *sxb = reinterpret_cast<char *>(sbias + nb + 32);         // x operand [tile][part][lane] x 16 B
     float *spart = reinterpret_cast<float *>(sxb + kTilesX * kStageBytes);   // [4 waves][kRowsX rows][33], shares LDS with the rings
@@ -1007,10 +972,8 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
     const char *gp = a.ws + (((size_t)agent * 4 + wave) * a.stages * P * 64 + lane) * 16;
     int pslot = 0;
     auto request_part = [&](int p) {                               // 1 KiB of the stage kRingX ahead
-#ifndef DRONESIM_ABL_X3_NODMA
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gp + p * 1024),
                                          (__attribute__((address_space(3))) void *)(ring + pslot * kStageBytes + p * 1024), 16, 0, 0);
-#endif
     };
     auto request_done = [&]() {
         gp += kStageBytes;
@@ -1114,12 +1077,10 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the partial sums reuse the rings: no DMA may land late
-#ifdef DRONESIM_TRACE
-    if (a.trace && lane == 0) {                                    // ... and when this wave's stream is done
+    if (kTrace && a.trace && lane == 0) {                          // ... and when this wave's stream is done
         a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 2] = __builtin_amdgcn_s_memtime();
         a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 3] = __builtin_amdgcn_s_memrealtime();
     }
-#endif
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < kTilesX; ++t)
@@ -1212,9 +1173,8 @@ int check_mlp(const char *who, int N, int d_in, int h1, int h2, int nout, int ou
 
 }   // namespace
 
-#if defined(DRONESIM_TRACE)
+// developer hook (tools/trace_policy.py / trace_x3.py with a -DDRONESIM_TRACE build; not declared in include/dronesim.h)
 extern "C" void dronesim_debug_set_policy_trace(long long *p) { g_policy_trace = p; }
-#endif
 
 extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                                          uint64_t seed, uint64_t counter, int64_t env_base,
@@ -1228,9 +1188,7 @@ extern "C" int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, 
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_bf16: NULL weight array");
     if (E == 0) return DRONESIM_OK;
     MArgsB a{};
-#if defined(DRONESIM_TRACE)
-    a.trace = g_policy_trace;
-#endif
+    a.trace = kTrace ? g_policy_trace : nullptr;
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2;
     a.nc1 = (m->h1 + 31) / 32; a.nc2 = (m->h2 + 31) / 32; a.ks1 = 1;
     a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
@@ -1312,9 +1270,7 @@ int mlp_forward_split(const char *what, const DroneMlpBf16 *m, const float *x, f
     }
     a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
     a.ws = reinterpret_cast<const char *>(m->w1p);
-#if defined(DRONESIM_TRACE)
-    a.trace = g_policy_trace;
-#endif
+    a.trace = kTrace ? g_policy_trace : nullptr;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
     // TILES = 4 (128-row workgroups, one per CU, accumulators in the AGPR half of a 512-register wave) builds and is
     // correct, but hipcc 7.2 places the accumulators badly (1100 v_accvgpr copies, scratch spills whose waits drain the
@@ -1350,9 +1306,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: fragment-packed w2 (w2_layout = 1) must be 16-byte aligned");
     if (E == 0) return DRONESIM_OK;
     MArgs a{};
-#if defined(DRONESIM_TRACE)
-    a.trace = g_policy_trace;
-#endif
+    a.trace = kTrace ? g_policy_trace : nullptr;
     a.E = E; a.N = m->N; a.d_in = m->d_in; a.h1 = m->h1; a.h2 = m->h2; a.nout = m->nout;
     a.x = x; a.w1 = m->w1; a.b1 = m->b1; a.w2 = m->w2; a.b2 = m->b2; a.w3 = m->w3; a.b3 = m->b3;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);

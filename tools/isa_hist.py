@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Static ISA instruction histogram of one drone_kernel instantiation, per source phase.
 
-Compiles csrc/dronesim.hip (one DRONESIM_PART) for gfx950 with `-save-temps -gline-tables-only` (line tables do not
+Compiles csrc/drone_kernel_k.hip (one k_closest value, -DDRONESIM_K) for gfx950 with `-save-temps -gline-tables-only` (line tables do not
 change code generation), takes the body of the requested kernel from the device assembly, maps every instruction to
 the source line its `.loc` names and buckets the lines by the `// @phase <name>` markers in the kernel source.
 Counts are STATIC (a loop body counts once); loop bodies are listed per phase so they can be weighted by hand.
 
-    python tools/isa_hist.py [--kernel drone_kernelILi2ELb0ELi0ELi1EE] [--part 1] [--out profiles/x.md] [--extra=-D...]
+    python tools/isa_hist.py [--kernel drone_kernelILi2ELb0ELi0ELi1EE] [--part 2] [--out profiles/x.md] [--extra=-D...]
 """
 import argparse
 import collections
@@ -16,7 +16,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "scalable_collision_avoidance_rl_amd", "csrc", "dronesim.hip")
+CSRC = os.path.join(ROOT, "scalable_collision_avoidance_rl_amd", "csrc")
+SRC = os.path.join(CSRC, "drone_kernel.hpp")          # the kernel source (phase markers, .loc lines)
+TU = os.path.join(CSRC, "drone_kernel_k.hip")         # the translation unit that instantiates it
 
 TRANS = ("v_sqrt", "v_log", "v_rsq", "v_rcp", "v_exp", "v_sin", "v_cos")
 CROSS = ("v_readlane", "v_readfirstlane", "v_writelane", "v_permlane", "v_bpermute", "ds_bpermute", "ds_permute", "ds_swizzle")
@@ -65,7 +67,7 @@ def phases_of_source():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kernel", default="drone_kernelILi2ELb0ELi0ELi1E")
-    ap.add_argument("--part", default="1")
+    ap.add_argument("--part", default="2", help="k_closest value (-DDRONESIM_K)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--extra", default="")
     ap.add_argument("--title", default=None)
@@ -73,10 +75,10 @@ def main():
     work = os.path.join(ROOT, "build", "isa")
     os.makedirs(work, exist_ok=True)
     cmd = ["hipcc", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-mllvm", "-amdgpu-kernarg-preload-count=8",
-           "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), f"-DDRONESIM_PART={args.part}",
-           "-gline-tables-only", "-save-temps", "-c", "-o", "isa_part.o", SRC] + ([args.extra] if args.extra else [])
+           "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), f"-DDRONESIM_K={args.part}", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+           "-gline-tables-only", "-save-temps", "-c", "-o", "isa_part.o", TU] + ([args.extra] if args.extra else [])
     subprocess.check_call(cmd, cwd=work)
-    asm = os.path.join(work, "dronesim-hip-amdgcn-amd-amdhsa-gfx950.s")
+    asm = os.path.join(work, "drone_kernel_k-hip-amdgcn-amd-amdhsa-gfx950.s")
     lines = open(asm).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(rf"^_Z\w*{re.escape(args.kernel)}\w*:", l))
     name = lines[start].split(":")[0]
@@ -85,7 +87,7 @@ def main():
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
         if m:
             file_ids[int(m.group(1))] = (m.group(3) or m.group(2))
-    src_ids = {k for k, v in file_ids.items() if v.endswith("dronesim.hip")}
+    src_ids = {k for k, v in file_ids.items() if v.endswith("drone_kernel.hpp")}
     ph = phases_of_source()
 
     def phase_of(line_no):
