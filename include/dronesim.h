@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DRONESIM_VERSION 301           /* 0.3.0: DroneEpisodeCtl grew z_final / nbr_final / pos_final */
+#define DRONESIM_VERSION 400           /* 0.4.0: dronesim_step_call (pre-marshalled step arguments) */
 #define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
 #define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
 
@@ -192,6 +192,28 @@ int dronesim_step_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, float *po
 int dronesim_rollout_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, float *pos, float *vel, int32_t *t,
                         const float *act, float *reward, float *true_reward, float *z, int32_t *nbr_idx,
                         int32_t *n_coll, uint8_t *done, int E, int T, void *stream);
+
+/* dronesim_step_ex with its arguments marshalled ONCE: a rollout loop calls step() with the same buffers every time
+ * (only the actions and, possibly, the stream change), and through an FFI that converts arguments one by one
+ * (ctypes, cgo, JNI) the 14-argument form costs more host time than the launch.  The host class keeps one
+ * DroneStepCall per (env, output binding) -- per storage slot when stepping into a RolloutStorage -- and makes a
+ * 3-argument call per step (drone_env.py:214, train_problem.py:94).  Same checks, same launch, same result.   */
+typedef struct DroneStepCall {
+    const DroneParams *p;
+    const DroneEpisodeCtl *ctl;         /* NULL = plain dronesim_step                                         */
+    float *pos;
+    float *vel;
+    int32_t *t;
+    float *reward;
+    float *true_reward;
+    float *z;
+    int32_t *nbr_idx;
+    int32_t *n_coll;
+    uint8_t *done;
+    int32_t E;
+    int32_t reserved;
+} DroneStepCall;
+int dronesim_step_call(const DroneStepCall *call, const float *act, void *stream);
 
 /* T fused steps whose actions are drawn INSIDE the kernel: RandomAgent.forward, SAC_agents.py:9-22
  * (clip(-1 + 2 rand(2), -1, 1)) for every agent and step, from the counter-based stream

@@ -24,7 +24,7 @@ MAX_AGENTS = 1024
 STATS_SCRATCH_DOUBLES = 769          # DRONESIM_STATS_SCRATCH_DOUBLES (include/dronesim.h)
 EPISODE_REDUCE_DOUBLES = 8           # DRONESIM_EPISODE_REDUCE_DOUBLES
 SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_episode_stats", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
-           "dronesim_step_ex", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
+           "dronesim_step_ex", "dronesim_step_call", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
            "dronesim_step_f64", "dronesim_observe_f64", "dronesim_mlp_forward_bf16x3", "dronesim_mlp_forward_f16x2", "dronesim_mlp_bf16x3_stages",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
@@ -53,6 +53,13 @@ class DroneEpisodeCtl(C.Structure):
     _fields_ = [("acc", C.c_void_p), ("auto_reset", C.c_int32), ("div_x", C.c_int32), ("div_y", C.c_int32),
                 ("pitch", C.c_float), ("seed", C.c_uint64), ("env_base", C.c_int64), ("episode", C.c_void_p),
                 ("z_final", C.c_void_p), ("nbr_final", C.c_void_p), ("pos_final", C.c_void_p)]
+
+
+class DroneStepCall(C.Structure):
+    """Mirror of `struct DroneStepCall` (include/dronesim.h): dronesim_step_ex's arguments, marshalled once."""
+    _fields_ = [("p", C.c_void_p), ("ctl", C.c_void_p), ("pos", C.c_void_p), ("vel", C.c_void_p), ("t", C.c_void_p),
+                ("reward", C.c_void_p), ("true_reward", C.c_void_p), ("z", C.c_void_p), ("nbr_idx", C.c_void_p),
+                ("n_coll", C.c_void_p), ("done", C.c_void_p), ("E", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DroneParamsF64(C.Structure):
@@ -128,6 +135,8 @@ def lib():
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
     PC = C.POINTER(DroneEpisodeCtl)
     L.dronesim_step_ex.argtypes = [P, PC] + [vp] * 10 + [i32, vp]
+    L.dronesim_step_call.argtypes = [vp, vp, vp]      # (plain integers: no per-call ctypes objects)
+    L.dronesim_step_call.restype = C.c_int
     L.dronesim_rollout_ex.argtypes = [P, PC] + [vp] * 10 + [i32, i32, vp]
     L.dronesim_rollout_random.argtypes = [P, PC] + [vp] * 10 + [i32, i32, vp]
     L.dronesim_reset_ex.argtypes = [P, PC] + [vp] * 5 + [i32, vp]

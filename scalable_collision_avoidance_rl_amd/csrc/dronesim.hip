@@ -620,6 +620,13 @@ int dronesim_step_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, float *po
     return launch(kStep, p, a, E, stream);
 }
 
+int dronesim_step_call(const DroneStepCall *c, const float *act, void *stream)
+{
+    if (!c) return fail(DRONESIM_EINVAL, "dronesim_step_call: call is NULL");
+    return dronesim_step_ex(c->p, c->ctl, c->pos, c->vel, c->t, act, c->reward, c->true_reward, c->z, c->nbr_idx,
+                            c->n_coll, c->done, c->E, stream);
+}
+
 int dronesim_step(const DroneParams *p, float *pos, float *vel, int32_t *t, const float *act,
                   float *reward, float *true_reward, float *z, int32_t *nbr_idx,
                   int32_t *n_coll, uint8_t *done, int E, void *stream)

@@ -194,6 +194,12 @@ class drones:
         self.global_action_space = N * dim
         self.local_action_space = dim
 
+        # per-step host path: current device / raw stream handle without building Stream objects
+        self._dev_index = self.device.index
+        self._step_call = self._lib.dronesim_step_call
+        self._cur_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+        raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._raw_stream = raw if raw is not None else (lambda i: torch.cuda.current_stream(i).cuda_stream)
         self._alloc()
         self.reset(renew_obstacles=False)
 
@@ -244,6 +250,7 @@ class drones:
         self.n_coll = torch.zeros(E, dtype=torch.int32, device=dev)
         self.done = torch.zeros(E, dtype=torch.uint8, device=dev)
         self._act = torch.zeros(E, N, 2, **f32)
+        self._act_shape = self._act.shape
         # terminal observation / state of the envs an auto-reset launch finishes (DroneEpisodeCtl.z_final ...)
         self.z_final = torch.zeros(E, N, K1 * c, **f32) if self.keep_final_obs else None
         self.nbr_final = torch.full((E, N, K1), -1, dtype=torch.int32, device=dev) if self.keep_final_obs else None
@@ -285,10 +292,24 @@ class drones:
             p.xF_lo = self._xF_lo.data_ptr()
             p.delta, p.radius = self._delta.data_ptr(), self._radius.data_ptr()
             self._params_cache = (key, p)
+            self._p_addr = C.addressof(p)             # what the pre-marshalled step calls point at
         return self._params_cache[1]
 
     def _stream(self):
         return C.c_void_p(self._torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _make_call(self, views, ctl):
+        """dronesim_step_ex's arguments for one output binding, marshalled ONCE (include/dronesim.h: DroneStepCall):
+        step() then makes a 3-argument call (call, actions, stream).  Returns ``[struct, address, ctl]`` -- the ctl
+        object is kept alive next to the struct that points at it."""
+        c = self._native.DroneStepCall()
+        c.p = self._p_addr
+        c.ctl = None if ctl is None else C.addressof(ctl)
+        c.pos, c.vel, c.t = self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr()
+        c.reward, c.true_reward = views["reward"].data_ptr(), views["true_reward"].data_ptr()
+        c.z, c.nbr_idx = views["z"].data_ptr(), views["nbr_idx"].data_ptr()
+        c.n_coll, c.done, c.E = views["n_coll"].data_ptr(), views["done"].data_ptr(), self.n_envs
+        return [c, C.addressof(c), ctl]
 
     def _make_ctl(self, z_final=None, nbr_final=None, pos_final=None):
         """A DroneEpisodeCtl of this env with the given terminal-observation targets (device tensors or None)."""
@@ -411,11 +432,11 @@ class drones:
         torch = self._torch
         if self.batched:
             act = actions
-            if not (torch.is_tensor(act) and act.dtype == torch.float32 and act.device == self.device
-                    and act.is_contiguous()):
+            if not (type(act) is torch.Tensor and act.dtype is torch.float32 and act.is_cuda and act.is_contiguous()
+                    and act.get_device() == self._dev_index):
                 act = torch.as_tensor(np.asarray(act, np.float32) if not torch.is_tensor(act) else act,
                                       dtype=torch.float32, device=self.device).contiguous()
-            if act.shape != self._act.shape:
+            if act.shape != self._act_shape:
                 raise ValueError(f"actions must be [{self.n_envs},{self.n_agents},2], got {tuple(act.shape)}")
         else:
             self._push_host_state()
@@ -423,14 +444,15 @@ class drones:
                            np.float32)
             self._act.copy_(torch.from_numpy(a).view(1, self.n_agents, 2), non_blocking=False)
             act = self._act
-        p = self._params()
-        # host fast path: the buffer addresses never change, so the argument list is built once (per storage slot
-        # when stepping into a RolloutStorage); only the action pointer and the current stream vary per call
+        self._params()                                   # (collision_weight is live: refreshes self._p_addr when it changed)
+        # host fast path: the buffer addresses never change, so dronesim_step_ex's arguments are marshalled once per output
+        # binding (per storage slot when stepping into a RolloutStorage) into a DroneStepCall; a step is a 3-argument
+        # call -- (call, actions, stream) as plain integers -- instead of 14 converted one by one
         if into is not None:
             if not self.batched:
                 raise ValueError("step(into=...) needs the batched (tensor) API")
             storage, slot = into
-            args, views = storage._slot(self, int(slot))
+            call, views = storage._slot(self, int(slot))
             av = views["actions"]
             if av is not None and act.data_ptr() != av.data_ptr():
                 av.copy_(act)                                # (a policy writing into storage.actions[t] avoids this)
@@ -438,22 +460,16 @@ class drones:
         else:
             if not self._bound_home:
                 self._bind(self._home, home=True)
-            args = self._step_args
-            if args is None:
-                h = self._home
-                args = self._step_args = [C.byref(p), C.byref(self._ctl()) if self._use_ctl else None] + [
-                    C.c_void_p(t.data_ptr()) for t in (
-                        self.pos, self.vel, self.t, self._act, h["reward"], h["true_reward"], h["z"], h["nbr_idx"],
-                        h["n_coll"], h["done"])] + [self.n_envs, None]
-        args[0] = C.byref(p)
-        args[5] = C.c_void_p(act.data_ptr())
-        if torch.cuda.current_device() == self.device.index:
-            args[13] = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            rc = self._lib.dronesim_step_ex(*args)
+            call = self._step_args
+            if call is None:
+                call = self._step_args = self._make_call(self._home, self._ctl() if self._use_ctl else None)
+        if call[0].p != self._p_addr:
+            call[0].p = self._p_addr
+        if self._cur_device() == self._dev_index:
+            rc = self._step_call(call[1], act.data_ptr(), self._raw_stream(self._dev_index))
         else:
             with torch.cuda.device(self.device):
-                args[13] = self._stream()
-                rc = self._lib.dronesim_step_ex(*args)
+                rc = self._step_call(call[1], act.data_ptr(), self._raw_stream(self._dev_index))
         if rc:
             self._native.check(rc, "dronesim_step")
         if self.batched:

@@ -89,7 +89,7 @@ class RolloutStorage:
         return self
 
     def _slot(self, env, t):
-        """(argument list of dronesim_step_ex, attribute views) of slot t -- built once, reused by every later pass."""
+        """(pre-marshalled DroneStepCall, attribute views) of slot t -- built once, reused by every later pass."""
         if env is not self.env:
             raise ValueError("this RolloutStorage belongs to another env")
         if not (0 <= t < self.T):
@@ -105,11 +105,9 @@ class RolloutStorage:
                          z_final=zf, nbr_final=nf, pos_final=env._home["pos_final"],
                          actions=None if self.actions is None else self.actions[t])
             ctl = env._make_ctl(zf, nf, env._home["pos_final"]) if env._use_ctl else None
-            args = [None, None if ctl is None else C.byref(ctl)] + [
-                C.c_void_p(x.data_ptr()) for x in (env.pos, env.vel, env.t, env._act, views["reward"], views["true_reward"],
-                                                   views["z"], views["nbr_idx"], views["n_coll"], views["done"])] + [env.n_envs, None]
-            self._slots[t] = (args, views, ctl)             # (the ctl object must outlive its byref)
-        return self._slots[t][0], self._slots[t][1]
+            env._params()
+            self._slots[t] = (env._make_call(views, ctl), views)   # (the call keeps its ctl object alive)
+        return self._slots[t]
 
     def next_z(self):
         """``new_z`` of every transition as the reference stores it (utils.py:244-249): the post-step observation,

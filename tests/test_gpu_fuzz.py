@@ -24,7 +24,7 @@ def torch():
     return torch
 
 
-@pytest.mark.parametrize("seed,iters,big_n", [(7, 50, False), (9, 50, False), (2026, 40, True)])
+@pytest.mark.parametrize("seed,iters,big_n", [(7, 150, False), (9, 150, False), (31, 150, False), (2026, 80, True), (2027, 80, True)])
 def test_rollout_fuzz_against_step_launches(torch, seed, iters, big_n):
     from scalable_collision_avoidance_rl_amd import drones, formation_O
     rng = np.random.default_rng(seed)
@@ -81,12 +81,12 @@ def test_rollout_fuzz_against_step_launches(torch, seed, iters, big_n):
 def test_big_shape_fuzz_against_oracle(torch, seed, monkeypatch):
     """tools/fuzz_big.sh of round 3: the shape fuzz of test_gpu_parity with up to 1024 agents and crowded boxes."""
     from tests import test_gpu_parity as P
-    monkeypatch.setenv("FUZZ_BIG", "1"); monkeypatch.setenv("FUZZ_SEED", str(seed)); monkeypatch.setenv("FUZZ_ITERS", "50")
+    monkeypatch.setenv("FUZZ_BIG", "1"); monkeypatch.setenv("FUZZ_SEED", str(seed)); monkeypatch.setenv("FUZZ_ITERS", "80")
     P.test_shape_fuzz_against_oracle(torch)
 
 
 @pytest.mark.parametrize("seed", [101, 202])
 def test_episode_layer_fuzz_more_seeds(torch, seed, monkeypatch):
     from tests import test_gpu_episodes as Ep
-    monkeypatch.setenv("FUZZ_SEED", str(seed)); monkeypatch.setenv("FUZZ_ITERS", "24")
+    monkeypatch.setenv("FUZZ_SEED", str(seed)); monkeypatch.setenv("FUZZ_ITERS", "60")
     Ep.test_episode_layer_shape_fuzz(torch)

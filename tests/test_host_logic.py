@@ -64,7 +64,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == sorted(_native.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dronesim_version() == 301
+    assert lib.dronesim_version() == 400
     assert lib.dronesim_error_string(0) == b"ok"
     assert b"invalid" in lib.dronesim_error_string(_native.EINVAL)
 
@@ -85,6 +85,9 @@ def test_episode_structs_match_header():
         body = header[header.index("typedef struct %s {" % name):header.index("} %s;" % name)]
         names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|int64_t|uint64_t|float|double|DroneEpisodeAcc)\s*\*?\s*(\w+);", body, re.M)
         assert names == [f[0] for f in cls._fields_], name
+    body = header[header.index("typedef struct DroneStepCall {"):header.index("} DroneStepCall;")]
+    names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|uint8_t|float|DroneParams|DroneEpisodeCtl)\s*\*?\s*(\w+);", body, re.M)
+    assert names == [f[0] for f in _native.DroneStepCall._fields_] and C.sizeof(_native.DroneStepCall) == 11 * 8 + 8
     assert C.sizeof(_native.DroneEpisodeAcc) == 64 and C.sizeof(_native.DroneEpisodeCtl) == 72
     assert _native.DroneEpisodeAcc.done_return.offset == 32 and _native.DroneEpisodeAcc.ep_len.offset == 20
     assert _native.DroneEpisodeCtl.seed.offset == 24 and _native.DroneEpisodeCtl.episode.offset == 40
