@@ -362,7 +362,14 @@ constexpr uint32_t kRandActKey = 0x52414E44u;   // "RAND": separates the action 
 //              ONCE (lane i tests partners i+1..i+32; the verdict reaches the partner as a rotated
 //              ballot), halving the far-filter arithmetic.
 //   kBlock256 / kBlock1024 : N > 64, one workgroup per env, thread = agent.
-enum Geo { kPacked = 0, kSym64 = 1, kBlock256 = 2, kBlock1024 = 3 };
+//   kBlockU256: kBlock256 specialised for N == 256 with uniform (d_hat, Delta, l) and no far agents (BASELINE configs[4]):
+//              four full waves per env, so lane masks, word counts, the LDS carve-up and the per-agent constants are
+//              compile-time / scalar (what kSym64 is to kPacked).  FUSED ROLLOUTS ONLY: there the per-step scalar
+//              bookkeeping it removes is 12-13 % of a step (C5 shard 2.46 -> 2.15 us per step, with in-kernel actions
+//              and the episode layer 3.32 -> 2.91; N = 256 x 4096 envs 13.8 -> 12.0); the single-step kernels measured
+//              +1 ... +6 % with it (their launch is a latency chain that the fully unrolled, hoisted form lengthens:
+//              profiles/r4_abtest_block_u256.log), so step / observe keep kBlock256.
+enum Geo { kPacked = 0, kSym64 = 1, kBlock256 = 2, kBlock1024 = 3, kBlockU256 = 4 };
 // Occupancy targets (waves per SIMD the launch bounds ask for; tools/kernel_resources.py lists what every instantiation got)
 constexpr int kSymStepWaves = 8;
 constexpr int kBlockStepWaves = 8;
@@ -386,8 +393,8 @@ template <int GEO> struct GeoTraits {
     static constexpr int min_waves(int k, int mode, bool epi, bool far)
     {
         const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves
-                                     : (GEO == kBlock256 && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
-                                     : (GEO == kBlock256 && epi) ? kBlockRolloutEpiWaves : 4;   // (the block rollout with the episode layer spills at 128 registers)
+                                                                          : ((GEO == kBlock256 || GEO == kBlockU256) && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
+                                     : ((GEO == kBlock256 || GEO == kBlockU256) && epi) ? kBlockRolloutEpiWaves : 4;   // (the block rollout with the episode layer spills at 128 registers)
         const int cap = k <= 2 ? 8 : k <= 4 ? 6 : 4;
         return want < cap ? want : cap;
     }
@@ -439,16 +446,19 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     constexpr bool WL = GeoTraits<GEO>::kWaveLocal;
     constexpr bool SYM = GEO == kSym64;
     // generic bucket filter (see below): always for N > 64, for packed envs when the host asks for it (N >= kBucketMinN)
-    constexpr bool BLOCKGEO = GEO == kBlock256 || GEO == kBlock1024;
-    constexpr int WMAX = GEO == kBlock1024 ? 16 : GEO == kBlock256 ? 4 : 1;   // 64-agent words per env
+    constexpr bool BU = GEO == kBlockU256;                   // N == 256, uniform constants: four FULL waves per env
+    constexpr bool B256 = GEO == kBlock256 || BU;            // workgroup-per-env, at most four 64-agent words
+    constexpr bool BLOCKGEO = B256 || GEO == kBlock1024;
+    constexpr int WMAX = GEO == kBlock1024 ? 16 : B256 ? 4 : 1;   // 64-agent words per env
+    static_assert(!(BU && FAR), "kBlockU256 assumes far agents never matter");
     static_assert(!(SYM && FAR), "the symmetric filter assumes far agents never matter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TRACE_MARK(0);
     const long long trace_rt0 = kTrace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, the same clock on every XCC
-    const int N = SYM ? 64 : a.N;
+    const int N = SYM ? 64 : BU ? 256 : a.N;
     const int tid = threadIdx.x;
     const unsigned lane = tid & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = BU ? 4 : blockDim.x >> 6;
     // Every wave covers a CONTIGUOUS range of global agents [wga0, wga0 + nval): lane l <-> agent wga0 + l.
     // wga0 / nval are wave-uniform (SGPRs), so every per-agent array is addressed as uniform base + lane.
     int slot, agent, env0, nval;
@@ -475,7 +485,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         slot = 0;
         agent = tid;
         env0 = (int)vb;
-        nval = max(0, min(kWave, N - wave * kWave));
+        nval = BU ? kWave : max(0, min(kWave, N - wave * kWave));
     }
     const size_t wga0 = (size_t)env0 * N + (WL ? 0 : wave * kWave);
     const int env = env0 + ((WL && !SYM) ? slot - wave * a.P : 0);
@@ -488,6 +498,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         if (nval == 0) return;
         if (masked && a.mask[env] == 0) return;
         valid = true;
+    } else if (BU) {
+        // four full waves of ONE env: a masked-out env's whole workgroup leaves (no barrier is left waiting), and in
+        // every other workgroup all 256 lanes are agents -- no lane masking anywhere below
+        if (masked && a.mask[env] == 0) return;
+        valid = true;
     } else {
         valid = (int)lane < nval;
         if (masked && valid) valid = a.mask[env] != 0;
@@ -496,7 +511,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // all agents share d_hat, Delta and radius (host-known): the constants are kernel-argument scalars.  kSym64 is only
     // chosen for such envs (launch()), so that its constants are wave-uniform at compile time: no per-agent loads, whose
     // return the early (hoisted) uses would otherwise wait for behind the state loads
-    const bool uniform = SYM || a.uniform != 0;
+    const bool uniform = SYM || BU || a.uniform != 0;
 
     // @phase loads
     // ---- longest-latency loads first: this agent's state (HBM), then the shared constants (L2)
@@ -616,7 +631,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // slack the crowded path's 16-partner reads may run into: 2.2 instead of 8.5 KB at N = 256)
     float2 *sconst_all = spos + (BLOCKGEO ? (size_t)block_pos_entries(N) : (size_t)a.epb * 2 * stride);   // [nconst][N + (N&1)]
     int *sred = reinterpret_cast<int *>(sconst_all + (size_t)nconst * (N + (N & 1)));      // [epb][2]
-    const int nred = 2 * a.epb + ((2 * a.epb) & 3 ? 4 - ((2 * a.epb) & 3) : 0);
+    const int epb_c = BLOCKGEO ? 1 : a.epb;                  // envs per workgroup
+    const int nred = 2 * epb_c + ((2 * epb_c) & 3 ? 4 - ((2 * epb_c) & 3) : 0);
     unsigned *sstage = reinterpret_cast<unsigned *>(sred + nred);
     // c = 2: [64][kZRow] z words + [64][kNRow] Ni words per wave; FAR with staged c = 5 rows: 5 (K+1) z words per lane
     const int zrow_w = (FAR && a.stage5) ? 5 * (K + 1) : kZRow;
@@ -642,7 +658,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     unsigned long long *sbx = SYM ? reinterpret_cast<unsigned long long *>(sym_block + 64 * 8 + 64 * 3 * (K + 1) * 4)
                                   : sbt_all + (size_t)wave * (2 * kCells);
     unsigned long long *sby = sbx + kCells;
-    const int W = BLOCKGEO ? nwaves : 1;
+    const int W = BU ? 4 : BLOCKGEO ? nwaves : 1;
     const bool use_bucket = !SYM && (BLOCKGEO || a.bucket != 0);                           // launch-uniform
     unsigned long long *sbt = sbt_all + (size_t)slot * (2 * kCells) * W;                   // this lane's env
     // tail (episode bookkeeping): per-wave partial reward sums [nwaves][2], then the sampling tables of the in-kernel
@@ -651,7 +667,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
 
     // (Delta_j, l_j) of a partner: kernel-argument scalars when all agents share them -- except in the fused
     // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
-    const bool uni_args = SYM || (MODE != kRollout && uniform);   // (kSym64: always uniform; scalar registers cost it nothing)
+    const bool uni_args = SYM || BU || (MODE != kRollout && uniform);   // (kSym64: always uniform; scalar registers cost it nothing)
     if (WL) {
         if (!SYM && (int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;   // kSym64 keeps these verdicts in scalar registers
         if (!uni_args && (int)lane < N)
@@ -696,7 +712,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // exact test in pass 2.
     // (round 3: also the workgroup-per-env rollout of up to 256 agents, CACHED_B -- same list, one 64-bit word per 64
     // partners, the "somebody moved" verdict agreed through an LDS word at the step's first barrier)
-    constexpr bool CACHED_B = GEO == kBlock256 && MODE == kRollout && !FAR;
+    constexpr bool CACHED_B = B256 && MODE == kRollout && !FAR;
     constexpr bool CACHED = (SYM && MODE == kRollout) || CACHED_B;
     const float thr_list = CACHED ? (reach + a.skin) * (reach + a.skin) * 1.000001f : thr;
     const float moved2 = 0.49f * a.skin * 0.49f * a.skin;
@@ -855,7 +871,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
 
         // @phase pass2_visit
         // pass 2 body: the pair (this agent, partner at index jdup of the doubled position array)
-        auto visit = [&](int jdup, auto defer, auto uni) {
+        auto visit = [&](int jdup, auto defer, auto uni) __attribute__((always_inline)) {
             const float2 pj = spos_env[jdup];
             const int j = jdup - ((jdup >= N) ? N : 0);
             // (Delta_j, l_j): `uni` = known at the call site to be the kernel-argument scalars (the hot walk is written
@@ -907,7 +923,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             unsigned long long first[WMAX];
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) first[w] = 0ull;
-            if (GEO == kBlock256 && !crowded) {
+            if (B256 && !crowded) {
                 float2 pf[WMAX];
                 int uf[WMAX];
 #pragma unroll
@@ -968,8 +984,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             TRACE_FINE(2);                                   // (-DDRONESIM_TRACE_FINE: candidates tested)
             // pass 2 over the verdicts, ascending agent order.  Workgroup-per-env geometries (ascending-order list):
             // the hot walk defers the general insertion and is written out for the uniform-(Delta, l) case, like kSym64's
-            auto walk = [&](auto defer, auto uni) {
-                if (GEO == kBlock256 && decltype(defer)::value) {
+            auto walk = [&](auto defer, auto uni) __attribute__((always_inline)) {
+                if (B256) {
                     // ONE loop over the verdicts of all words (every lane takes its own lowest partner per trip): a trip
                     // costs the wave a dependent LDS read and ~60 VALU whatever the number of lanes that take part, and
                     // the few partners of a sparse env are spread over the words
@@ -1224,6 +1240,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         // @phase epilogue_rewards_z
         float r_out = 0.0f, tr_out = 0.0f;                    // this lane's rewards (episode bookkeeping)
         float r_env = 0.0f, tr_env = 0.0f;                    // their sums over the env, valid in its agent-0 lane
+        float2 sm_blk = make_float2(0.f, 0.f);                // workgroup-per-env: this wave's partial sums
         int coll_s = 0;                                       // kSym64: the env's collisions / agents outside the goal
         unsigned long long outside_m = 0ull;                  //         disk, wave-uniform (scalar registers)
         // fused rollout: the next step's action (prefetched at the top of this step) is waited for HERE, ahead of the
@@ -1245,6 +1262,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                                                               // run-time `has_acc`: a branch would fence the dependent
                 const float2 sm = wave_sum64_pair(r_out, tr_out);   // chain off from the row arithmetic below, which fills
                 r_env = sm.x; tr_env = sm.y;                  // its wait states
+            } else if (!WL && EPI && nval == kWave) {
+                // workgroup-per-env, a full wave (wave-uniform test: all 64 lanes are here): the same fixed-order tree, taken
+                // HERE so that the row arithmetic below fills the wait states of its dependent chain (round 4; it sat
+                // behind the rows, in front of the staging, where nothing overlaps it)
+                sm_blk = wave_sum64_pair(r_out, tr_out);
             }
 
             // localized state rows + neighbour list (:344-397)
@@ -1342,8 +1364,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         // geometries leave one partial per wave in LDS ahead of the barrier below; wave-local geometries reduce after
         // their output stores have been issued (the reduction is a dependent chain: nothing should queue behind it)
         if (!WL && has_acc) {
-            const float2 sm = wave_sum64_pair(r_out, tr_out);
-            if (lane == 0) { spart[2 * wave] = sm.x; spart[2 * wave + 1] = sm.y; }
+            if (nval != kWave) sm_blk = wave_sum64_pair(r_out, tr_out);   // (a ragged last wave: lanes without an agent carry 0)
+            if (lane == 0) { spart[2 * wave] = sm_blk.x; spart[2 * wave + 1] = sm_blk.y; }
         }
         // @phase stage_and_copy_out
         if (staged && valid && zc == 2) {                     // this lane's rows -> the wave's staging area
@@ -1373,7 +1395,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             gu32x4 *gz4 = (gu32x4 *)gzg, *gn4 = (gu32x4 *)gng;
             // fixed-shape copy: a full wave of agents whose rows start 16-byte aligned -- always for kSym64 (checked on
             // the host), every full wave of the workgroup-per-env geometries otherwise (wave-uniform test)
-            const bool fixed = SYM || (BLOCKGEO && !(FAR && zc == 5) && nval == kWave &&
+            const bool fixed = SYM || BU || (BLOCKGEO && !(FAR && zc == 5) && nval == kWave &&
                                        ((reinterpret_cast<uintptr_t>(gz) | reinterpret_cast<uintptr_t>(gn)) & 15u) == 0);
             if (!kTrace && (SYM || BLOCKGEO)) asm volatile("" : "+s"(gz4), "+s"(gn4));   // (the trace build's stamps make hipcc lose the uniformity)
             if (fixed) {
@@ -1427,6 +1449,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         } else
         if (valid && (agent == 0 || (has_acc && agent == 1))) {
             const int2 red = *reinterpret_cast<const int2 *>(sred + 2 * slot);   // (collisions, someone outside the goal disk)
+            // up to four waves: all partial sums are requested together with the verdict words (one LDS round trip; the
+            // region behind the partials belongs to the episode layer's sampling tables, so 32 bytes are always there)
+            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+            if (B256 && has_acc && agent == 0) {
+                pa = reinterpret_cast<const float4 *>(spart)[0];
+                pb = reinterpret_cast<const float4 *>(spart)[1];
+            }
             const int coll_env = red.x;
             if (agent == 0) {
                 const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
@@ -1438,7 +1467,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     fin_env = fin;
                 }
                 if (has_acc) {                                    // train_problem.py:98-99, every step
-                    if (!WL) {
+                    if (B256) {                                   // wave order, like the loop below
+                        r_env += pa.x; tr_env += pa.y;
+                        if (nwaves > 1) { r_env += pa.z; tr_env += pa.w; }
+                        if (nwaves > 2) { r_env += pb.x; tr_env += pb.y; }
+                        if (nwaves > 3) { r_env += pb.z; tr_env += pb.w; }
+                    } else if (!WL) {
                         for (int w = 0; w < nwaves; ++w) { r_env += spart[2 * w]; tr_env += spart[2 * w + 1]; }
                     }
                     const double nr = __builtin_bit_cast(double, make_uint2(accw.x, accw.y)) + (double)r_env;
@@ -1751,6 +1785,10 @@ hipError_t launch_k(int mode, bool far, const KArgs &a, const Geometry &g, hipSt
         return far ? launch_mode<K, true, kPacked>(mode, a, g, s) : launch_mode<K, false, kPacked>(mode, a, g, s);
     case kBlock256:
         return far ? launch_mode<K, true, kBlock256>(mode, a, g, s) : launch_mode<K, false, kBlock256>(mode, a, g, s);
+    case kBlockU256: {                              // rollouts only (launch() picks it for mode == kRollout)
+        const bool epi = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;
+        return epi ? launch_one<K, false, kRollout, kBlockU256, true>(a, g, s) : launch_one<K, false, kRollout, kBlockU256, false>(a, g, s);
+    }
     default:
         return far ? launch_mode<K, true, kBlock1024>(mode, a, g, s) : launch_mode<K, false, kBlock1024>(mode, a, g, s);
     }

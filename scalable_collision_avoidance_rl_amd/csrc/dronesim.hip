@@ -545,6 +545,10 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     a.uniform = (p->d_hat_min == p->d_hat_max && p->delta_min == p->delta_max && p->radius_min == p->radius_max) ? 1 : 0;
     if (p->N == 64 && !far && a.uniform && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
         g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane; uniform (d_hat, Delta, radius) only
+    // N = 256 with uniform constants (BASELINE configs[4]), fused rollouts: the workgroup-per-env kernel with four full waves known at compile time
+    if (mode == kRollout && g.geo == kBlock256 && p->N == 256 && !far && a.uniform &&
+        ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
+        g.geo = kBlockU256;
     const bool epi_regions = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;   // the episode layer's regions: only when in use
     const size_t tail = epi_regions ? drone_lds_tail_bytes(g, p->N) : 0;
     // kSym64 has its own carve-up: one block per wave (positions, staging area, cell tables)
