@@ -395,7 +395,7 @@ template <int GEO> struct GeoTraits {
         const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves
                                                                           : ((GEO == kBlock256 || GEO == kBlockU256) && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
                                      : ((GEO == kBlock256 || GEO == kBlockU256) && epi) ? kBlockRolloutEpiWaves : 4;   // (the block rollout with the episode layer spills at 128 registers)
-        const int cap = k <= 2 ? 8 : k <= 4 ? 6 : 4;
+        const int cap = k <= 2 ? 8 : k <= 4 ? (((far || epi) && GEO == kBlock256 && mode != kRollout) ? 5 : 6) : 4;   // (k = 3 / 4, FAR or episode layer: 8-12 B of spills at 80 registers)
         return want < cap ? want : cap;
     }
     static constexpr bool kWaveLocal = GEO == kPacked || GEO == kSym64;

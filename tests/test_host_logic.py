@@ -244,9 +244,9 @@ def test_bf16_fragment_packing_layouts():
 
 def test_no_step_kernel_spills():
     """Registers / scratch of every instantiation of the BUILT library (tools/kernel_resources.py reads the gfx950 code
-    objects): the single-step and observe kernels of every k <= 7 -- the BASELINE configs are k = 2 -- use no scratch
-    at all (a spill on the hot path is a silent 2x; a register-budget change must not introduce one), the two k = 8
-    instantiations that touch scratch stay within a few dwords, and the headline kernels fit their occupancy targets."""
+    objects): the single-step and observe kernels -- the BASELINE configs are k = 2 -- use no scratch at all (a spill on
+    the hot path is a silent 2x; a register-budget change must not introduce one; this test caught two in round 4), bar the
+    k >= 7 episode-layer kernels of N > 256, and the headline kernels fit their occupancy targets."""
     import shutil
     from tools import kernel_resources as KR
     if not os.path.exists(KR.READELF) and not shutil.which(KR.READELF):
@@ -256,8 +256,9 @@ def test_no_step_kernel_spills():
     assert len(rows) >= 200                                   # 8 k x geometries x modes x episode layer
     step = [r for r in rows if r[1]["mode"] in (0, 1)]
     spilled = [(r[0], r[4]) for r in step if r[4] != 0]
-    assert all(r[1]["k"] == 8 and r[4] <= 32 for r in step if r[4] != 0), spilled
-    assert not [s for s in spilled if "K=8" not in s[0]], spilled
+    # the only step kernels that touch scratch: N > 256 (1024-thread workgroups: 128 registers are the hard cap there) with
+    # the episode layer at k >= 7, a few dwords
+    assert all(r[1]["k"] >= 7 and r[1]["geo"] == 3 and r[1]["epi"] == 1 and r[4] <= 64 for r in step if r[4] != 0), spilled
     by = {(r[1]["k"], r[1]["far"], r[1]["mode"], r[1]["geo"], r[1]["epi"]): r for r in rows}
     # C3's graded kernel (kSym64 step, episode layer) and its plain form: 8 waves per SIMD = at most 64 VGPRs
     assert by[(2, 0, 0, 1, 1)][2] <= 64 and by[(2, 0, 0, 1, 0)][2] <= 64
