@@ -147,13 +147,20 @@ def step_kernel_ms(torch, env, pool, n_samp, reps=10):
     return float(np.median(samples))
 
 
-def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precision="f32"):
+def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precision="f32", default_construction=False):
     """One of the other BASELINE configs, timed in this process after the graded region: the same step path
-    (episode layer, hipGraph replay), single GPU.  Returns the block appended under `other_workloads`."""
+    (episode layer, hipGraph replay), single GPU.  Returns the block appended under `other_workloads`.
+    ``default_construction``: the reference's own defaults `drones(n, 0, grid, "O")` -- deltas=None (Delta = d_hat),
+    simplify_zstate=False (15-column observation: 112 B per agent-step) -- drone_env.py:55, 85-87, 184."""
     from scalable_collision_avoidance_rl_amd import drones, max_time_steps
     N, E, G, delta, label = WORKLOADS[name]
-    env = drones(N, 0, [G, G], "O", k_closest=2, deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, device=dev,
-                 seed=1234, batched=True, auto_reset=True, track_episodes=True)
+    if default_construction:
+        env = drones(N, 0, [G, G], "O", n_envs=E, device=dev, seed=1234, batched=True, auto_reset=True, track_episodes=True)
+        label = (f"reference defaults drones({N}, 0, [{G:g}, {G:g}], 'O'): deltas=None, simplify_zstate=False, k_closest=2; "
+                 f"{E} envs/GPU, random actions")
+    else:
+        env = drones(N, 0, [G, G], "O", k_closest=2, deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, device=dev,
+                     seed=1234, batched=True, auto_reset=True, track_episodes=True)
     T_ep = max_time_steps
     g = torch.Generator(device=dev).manual_seed(99)
     pool = torch.rand(T_ep, E, N, 2, device=dev, generator=g) * 2 - 1
@@ -185,14 +192,14 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
     el = time.perf_counter() - t0
     steps = L * repeats
     kern_ms = step_kernel_ms(torch, env, pool, 5 * T_ep, reps=5)
-    byt = algorithmic_bytes(N, E, True)
+    byt = algorithmic_bytes(N, E, True) + (36 * N * E if default_construction else 0)      # c = 5 rows: 60 B of z instead of 24
     arith = {"f32": "exact float32 (v_mfma_f32_32x32x2_f32)", "bf16x3": "float32-accurate three-part bf16 split (6 x v_mfma_f32_32x32x16_bf16 per 16 k)"}.get(precision, precision)
     out = {"workload": label + (f" + {policy_kind} policy in the loop, {arith} (BASELINE configs[4], one shard)" if policy else ""),
            "value": N * E * steps / el, "unit": "agent-steps/s", "ms_per_step": el / steps * 1e3, "timed_steps": steps,
            "timed_seconds": el, "step_kernel_ms": kern_ms,
            "roofline": {"bound": "hbm", "achieved": byt / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": byt / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byt,
-                        "kernel": "drone_kernel<K=2,FAR=0,step,episode layer>"}}
+                        "kernel": "drone_kernel<K=2,FAR=%d,step,episode layer>" % (1 if default_construction else 0)}}
     if policy is not None:                             # the policy kernel alone (exact-f32 MFMA), same events-around-a-graph method
         pg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(pg):
@@ -590,7 +597,11 @@ def main():
                                   f"batched per-agent {args.policy} policy (random-init, {args.policy_precision} MFMA) on the observation",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # SURVEY.md 8(d) bytes only (76 B per agent-step + 13 B per env-step, no episode-record bytes)
+                         "frac_survey_bytes": algorithmic_bytes(N, E, False) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "survey_bytes_per_launch": algorithmic_bytes(N, E, False),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "drone_kernel<K=2,FAR=0,step,%s>" % ("episode layer" if layer else "plain"), "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
             "exchange": {"what": "per-episode log of train_problem.py:118-121: fixed-order reduction of the per-env episode "
@@ -638,9 +649,10 @@ def main():
             torch.cuda.empty_cache()
             other = {}
             for key, wl, pk, pr in (("c2", "c2", None, "f32"), ("c5_env", "c5", None, "f32"),
+                                    ("default_construction", "c3", None, "f32"),
                                     ("c5_gaussian_f32", "c5", "gaussian", "f32"), ("c5_gaussian_bf16x3", "c5", "gaussian", "bf16x3")):
                 try:
-                    other[key] = side_workload(torch, dev, wl, pk, precision=pr)
+                    other[key] = side_workload(torch, dev, wl, pk, precision=pr, default_construction=(key == "default_construction"))
                 except Exception as ex:                 # a side measurement must never cost the headline line
                     other[key] = {"error": f"{type(ex).__name__}: {ex}"}
             out["other_workloads"] = other

@@ -404,7 +404,8 @@ template <int GEO> struct GeoTraits {
 // workgroup-per-env geometries: float2 entries of the position tile (N, the over-read slack, even for 16-byte alignment)
 __host__ __device__ constexpr int block_pos_entries(int N) { return (N + kPad + 1) & ~1; }
 // kSym64's LDS block per wave: [64 positions][staging: 64 x (z row + Ni row)][x cells | y cells] -- see the carve-up
-constexpr int sym_wave_bytes(int K) { return 64 * 8 + 64 * 3 * (K + 1) * 4 + 2 * kCells * 8; }
+// (zc = columns of a staged z row: 2, or 5 for the FAR variant with c = 5 rows)
+constexpr int sym_wave_bytes(int K, int zc = 2) { return 64 * 8 + 64 * (zc + 1) * (K + 1) * 4 + 2 * kCells * 8; }
 
 template <bool WAVE_LOCAL>
 __device__ __forceinline__ void group_sync()
@@ -451,7 +452,6 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     constexpr bool BLOCKGEO = B256 || GEO == kBlock1024;
     constexpr int WMAX = GEO == kBlock1024 ? 16 : B256 ? 4 : 1;   // 64-agent words per env
     static_assert(!(BU && FAR), "kBlockU256 assumes far agents never matter");
-    static_assert(!(SYM && FAR), "the symmetric filter assumes far agents never matter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TRACE_MARK(0);
     const long long trace_rt0 = kTrace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, the same clock on every XCC
@@ -643,7 +643,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // verdict words; the doubled / shifted position copies of the crowded fallback, which only it reads, run on from the
     // 64 positions INTO the staging area (and, for k = 1, the cell tables, which are dead by then): the staging area is
     // not written before the epilogue, and the rows' neighbour positions are read from the first 64 entries only.
-    char *const sym_block = smem + (size_t)wave * sym_wave_bytes(K);
+    const int sym_zc = (FAR && a.stage5) ? 5 : 2;            // (FAR: the reference's default construction at N = 64, round 4)
+    char *const sym_block = smem + (size_t)wave * sym_wave_bytes(K, sym_zc);
     if (SYM) stage_z = reinterpret_cast<unsigned *>(sym_block + 64 * 8);
     unsigned *stage_n = stage_z + kWave * zrow_w;
     float2 *sconst = sconst_all + (WL ? (size_t)wave * (N + (N & 1)) : 0);
@@ -655,7 +656,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // table and reads cells c-1, c, c+1 without a guard row or an edge test.  (Round 2 kept (x, y) pairs at a 16-byte
     // stride: cells c and c + 8 then shared their banks -- 2-3 way conflicts on the ds_or / ds_read of every launch,
     // 40 % of the kernel's LDS cycles; at 8 bytes per cell the 23 cells of C3 are conflict-free.)
-    unsigned long long *sbx = SYM ? reinterpret_cast<unsigned long long *>(sym_block + 64 * 8 + 64 * 3 * (K + 1) * 4)
+    unsigned long long *sbx = SYM ? reinterpret_cast<unsigned long long *>(sym_block + 64 * 8 + 64 * (sym_zc + 1) * (K + 1) * 4)
                                   : sbt_all + (size_t)wave * (2 * kCells);
     unsigned long long *sby = sbx + kCells;
     const int W = BU ? 4 : BLOCKGEO ? nwaves : 1;
@@ -713,7 +714,8 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // (round 3: also the workgroup-per-env rollout of up to 256 agents, CACHED_B -- same list, one 64-bit word per 64
     // partners, the "somebody moved" verdict agreed through an LDS word at the step's first barrier)
     constexpr bool CACHED_B = B256 && MODE == kRollout && !FAR;
-    constexpr bool CACHED = (SYM && MODE == kRollout) || CACHED_B;
+    // (not for FAR: its far tail needs the EXACT near set, and a listed-but-currently-far partner is not in it)
+    constexpr bool CACHED = (SYM && !FAR && MODE == kRollout) || CACHED_B;
     const float thr_list = CACHED ? (reach + a.skin) * (reach + a.skin) * 1.000001f : thr;
     const float moved2 = 0.49f * a.skin * 0.49f * a.skin;
     const float inv_cell = __builtin_amdgcn_rcpf((CACHED ? (SYM ? reach : a.reach_max) + a.skin : a.reach_max) * 1.001f);   // bucket filter: cells a little wider than the list radius
@@ -737,7 +739,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // formed in the shadow of the state loads, like the scalar side above
     unsigned long long self_bit = 1ull << lane;              // this lane's bit in the cell masks of the bucket filter
     // partners reach pass 2 in ascending agent order on every path of these geometries (bucket / symmetric filter)
-    constexpr bool ASC = SYM || (BLOCKGEO && !FAR);
+    constexpr bool ASC = (SYM || BLOCKGEO) && !FAR;
     // start values of pass 2 (row sums, collision count, the neighbour list holding the agent itself): in a single-step
     // launch they are register values set up early as well -- as rematerialisable constants the compiler sets them twice
     // on the critical path (once around and once inside the wave's "does any lane have a partner" branch)
@@ -1065,7 +1067,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     //     candidates = (x masks) & (y masks).  Coordinates beyond the 64 cells clamp to the end
                     //     cells, which only ever adds candidates.  ~35 instructions instead of 32 offsets x 5+.
                     const unsigned long long self = self_bit;
-                    if (CACHED) { sbx[lane] = 0ull; sby[lane] = 0ull; }       // (step / observe: zeroed ahead of the loads' return)
+                    if (CACHED || MODE == kRollout) { sbx[lane] = 0ull; sby[lane] = 0ull; }   // (step / observe: zeroed ahead of the loads' return)
                     const int cx = (int)fminf(fmaxf(fmaf(xi, inv_cell, 1.0f), 1.0f), 62.0f);
                     const int cy = (int)fminf(fmaxf(fmaf(yi, inv_cell, 1.0f), 1.0f), 62.0f);
                     group_sync<true>();
@@ -1159,6 +1161,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 // @phase pass2_walk
                 // ---- pass 2: every lane walks its own surviving partners
                 if (SYM) {
+                    if (FAR) vis[0] = near;                   // (absolute agent indices already)
                     // hot walk with the deferred neighbour list; a wave that met a partner at or inside its agent's own
                     // entry (coincident agents, a larger partner over a smaller agent's centre) starts over with the
                     // general insertion, out of line
@@ -1395,7 +1398,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             gu32x4 *gz4 = (gu32x4 *)gzg, *gn4 = (gu32x4 *)gng;
             // fixed-shape copy: a full wave of agents whose rows start 16-byte aligned -- always for kSym64 (checked on
             // the host), every full wave of the workgroup-per-env geometries otherwise (wave-uniform test)
-            const bool fixed = SYM || BU || (BLOCKGEO && !(FAR && zc == 5) && nval == kWave &&
+            const bool fixed = (SYM && !(FAR && zc == 5)) || BU || (BLOCKGEO && !(FAR && zc == 5) && nval == kWave &&
                                        ((reinterpret_cast<uintptr_t>(gz) | reinterpret_cast<uintptr_t>(gn)) & 15u) == 0);
             if (!kTrace && (SYM || BLOCKGEO)) asm volatile("" : "+s"(gz4), "+s"(gn4));   // (the trace build's stamps make hipcc lose the uniformity)
             if (fixed) {
@@ -1780,7 +1783,7 @@ template <int K>
 hipError_t launch_k(int mode, bool far, const KArgs &a, const Geometry &g, hipStream_t s)
 {
     switch (g.geo) {
-    case kSym64: return launch_mode<K, false, kSym64>(mode, a, g, s);
+    case kSym64: return far ? launch_mode<K, true, kSym64>(mode, a, g, s) : launch_mode<K, false, kSym64>(mode, a, g, s);
     case kPacked:
         return far ? launch_mode<K, true, kPacked>(mode, a, g, s) : launch_mode<K, false, kPacked>(mode, a, g, s);
     case kBlock256:

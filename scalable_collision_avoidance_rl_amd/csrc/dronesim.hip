@@ -543,8 +543,10 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     // when a clipped distance can pass a Delta mask (Delta_j >= dhat_i possible)
     const bool far = (p->c == 5) || !(p->delta_max < p->d_hat_min);
     a.uniform = (p->d_hat_min == p->d_hat_max && p->delta_min == p->delta_max && p->radius_min == p->radius_max) ? 1 : 0;
-    if (p->N == 64 && !far && a.uniform && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
-        g.geo = kSym64;                 // its fixed-shape copy-out stores 16 bytes per lane; uniform (d_hat, Delta, radius) only
+    // one env per wave, uniform (d_hat, Delta, radius) only; its fixed-shape copy-out of c = 2 rows stores 16 bytes per lane.
+    // Round 4: also the FAR variant -- the reference's DEFAULT construction (deltas=None, simplify_zstate=False) at N = 64
+    if (p->N == 64 && a.uniform && ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
+        g.geo = kSym64;
     // N = 256 with uniform constants (BASELINE configs[4]), fused rollouts: the workgroup-per-env kernel with four full waves known at compile time
     if (mode == kRollout && g.geo == kBlock256 && p->N == 256 && !far && a.uniform &&
         ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
@@ -554,7 +556,11 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     // kSym64 has its own carve-up: one block per wave (positions, staging area, cell tables)
     g.lds = g.geo == kSym64 ? (size_t)(g.threads / kWave) * sym_wave_bytes(p->k) : drone_lds_bytes(g, p->N, p->k);
     a.stage5 = 0; a.lds_vel = 0;
-    if (p->c == 5) {
+    if (p->c == 5 && g.geo == kSym64) {                 // per-wave blocks with 5-column rows, then the waves' velocities
+        a.stage5 = 1;
+        a.lds_vel = (int)((size_t)(g.threads / kWave) * sym_wave_bytes(p->k, 5));
+        g.lds = (size_t)a.lds_vel + sizeof(float2) * (size_t)g.epb * (size_t)p->N;
+    } else if (p->c == 5) {
         // c = 5 rows: staged through LDS like the c = 2 ones, and the agents' velocities kept in LDS for the rows of the k
         // nearest, when the env's tile still fits (it does up to N = 1024 at k <= 5; the rows leave as 4-byte stores at a
         // 60-byte stride otherwise, as they all did through round 2)

@@ -281,9 +281,10 @@ def test_step_matches_oracle(torch, cfg):
     np.testing.assert_array_equal(host(nbc), cnt)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x2"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16x2"])
 def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch, prec):
-    """(exact-float32 policy kernel, and the float16-split one that the C5 bench line is quoted with.)
+    """(exact-float32 policy kernel and the three-part bf16 split -- the two precisions the C5 bench lines are quoted with --
+    plus the opt-in float16 split.)
     BASELINE configs[4] as it is stated: n = 256 agents x 512 envs (one GPU's shard of 4096), Delta = 2.5, G = 256,
     actions from a continuous Gaussian policy -- the batched per-agent NormalActorNN (6 -> 400 -> (200 | 200) ->
     tanh mu[2] | sigmoid var[2], utils.py:55-117) evaluated on the env's own observation every step.
