@@ -8,6 +8,13 @@ constexpr bool kTrace = true;
 #else
 constexpr bool kTrace = false;
 #endif
+// -DDRONESIM_TRACE_SPAN: ONLY the entry / exit time of every wave on the chip-wide 100 MHz clock (s_memrealtime), with the product's
+// code otherwise unchanged (hoisting on): first-wave-in -> last-wave-out span of a launch inside a graph replay (tools/trace_span.py)
+#if defined(DRONESIM_TRACE_SPAN)
+constexpr bool kTraceSpan = true;
+#else
+constexpr bool kTraceSpan = false;
+#endif
 #if defined(DRONESIM_TRACE_FINE)
 constexpr bool kTraceFine = true;
 #else

@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     static_assert(!(BU && FAR), "kBlockU256 assumes far agents never matter");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     TRACE_MARK(0);
-    const long long trace_rt0 = kTrace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, the same clock on every XCC
+    const long long trace_rt0 = (kTrace || kTraceSpan) ? (long long)__builtin_amdgcn_s_memrealtime() : 0;   // 100 MHz, the same clock on every XCC
     const int N = SYM ? 64 : BU ? 256 : a.N;
     const int tid = threadIdx.x;
     const unsigned lane = tid & (kWave - 1);
@@ -1721,6 +1721,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
 #undef has_acc
 #undef auto_reset
     TRACE_MARK(5);
+    if (kTraceSpan && a.trace && (threadIdx.x & 63) == 0)        // one word per wave: entry (low) | exit (high), stores NOT waited for
+        a.trace[(size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] =
+            (trace_rt0 & 0xffffffffll) | ((long long)__builtin_amdgcn_s_memrealtime() << 32);
     if (kTrace) {
         __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): all stores acknowledged
         TRACE_MARK(6);
