@@ -432,3 +432,43 @@ def test_state_injection_does_not_clobber_a_bound_storage_slot(torch):
     for n, v in keep.items():
         assert torch.equal(getattr(st, n), v), n
     assert env.z.data_ptr() == env._home["z"].data_ptr() and torch.equal(env.z, z_now)
+
+
+@pytest.mark.parametrize("N,G,E,k,c,default_delta", [(64, 28.0, 64, 2, 2, False), (5, 5.0, 200, 2, 2, False), (130, 130.0, 8, 2, 2, False),
+                                                      (256, 256.0, 6, 2, 2, False), (300, 300.0, 3, 3, 2, False), (9, 8.0, 40, 2, 5, False),
+                                                      (64, 28.0, 20, 3, 5, False), (48, 24.0, 30, 4, 2, False)], ids=lambda v: str(v))
+@pytest.mark.parametrize("entry", ["rollout", "rollout_random", "step"])
+def test_reobservation_after_in_kernel_reset_matches_the_oracle(torch, N, G, E, k, c, default_delta, entry):
+    """ORACLE evidence for the cold path (the rollout == step tests are HIP against HIP): every env's episode
+    ends in the LAST step of a fused rollout (or in a single step), so what the launch leaves in z / nbr_idx is the
+    in-kernel re-observation of the freshly drawn state (drone_env.py:208-210 after :98-102) -- compared with the float64
+    oracle's observation of that state, neighbour ids exactly (drone_env.py:346, 362-365)."""
+    deltas = None if default_delta else np.ones(N)
+    from scalable_collision_avoidance_rl_amd import drones
+    env = drones(N, 0, [G, G], "O", k_closest=k, deltas=deltas, simplify_zstate=(c == 2), n_envs=E, batched=True,
+                 device="cuda:0", seed=77, auto_reset=True)
+    orc = Oracle(N, [G, G], k, deltas, c == 2, threads=4)
+    T = 6
+    env.t.fill_(200 - T if entry != "step" else 199)
+    if entry == "rollout":
+        g = torch.Generator(device="cuda:0").manual_seed(3)
+        out = env.rollout(torch.rand(T, E, N, 2, device="cuda:0", generator=g) * 2 - 1)
+        z, nb, done = out["z"][-1], out["nbr_idx"][-1], out["done"]
+        assert not bool(done[:-1].any())
+    elif entry == "rollout_random":
+        out = env.rollout_random(T)
+        z, nb, done = out["z"][-1], out["nbr_idx"][-1], out["done"]
+    else:
+        res = env.step(torch.rand(E, N, 2, device="cuda:0") * 2 - 1)
+        z, nb, done = res.z_states, env.nbr_idx, res.finished[None]
+    torch.cuda.synchronize()
+    assert bool(done[-1].all()) and int(env.t.abs().max()) == 0 and int(env.vel.abs().max()) == 0
+    p = host(env.pos).astype(np.float64)
+    ref = orc.observe(p, np.zeros_like(p))
+    safe = orc.margins(p) > H.MARGIN
+    assert safe.mean() > 0.5
+    np.testing.assert_array_equal(host(nb)[safe], ref["nbr_idx"][safe])
+    zz = host(z).reshape(E, N, k + 1, c)
+    m = H.z_compare_mask(ref["nbr_idx"], np.ones((E, N), bool) if not default_delta else np.zeros((E, N), bool), c)
+    H.assert_close(np.where(m, zz, 0)[safe], np.where(m, ref["z"], 0)[safe], "re-observed z", atol=H.atol_coord(G))
+    assert torch.equal(env.z, z) and torch.equal(env.nbr_idx, nb)
