@@ -940,6 +940,34 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     pool[w] &= pool[w] - 1ull;
                 }
             }
+            if (B256 && !crowded) {
+                // the candidates BEHIND every word's first one: ONE loop over all words, every lane taking its own lowest
+                // remaining candidate per trip (the shape of the pass-2 walk).  One loop per word (through round 3) cost the
+                // wave a dependent LDS round trip per word in which ANY lane had a second candidate -- nearly every word:
+                // 1084 of a C5 wave's 7700 cycles (per-wave stamps, profiles/r4_trace_fine_c5.log)
+                unsigned long long left = 0ull;
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) left |= pool[w];
+                while (left != 0ull) {
+                    unsigned long long hs = pool[WMAX - 1];
+                    int ws = WMAX - 1;
+#pragma unroll
+                    for (int w = WMAX - 2; w >= 0; --w) { if (pool[w] != 0ull) { hs = pool[w]; ws = w; } }
+                    const int u = __builtin_ctzll(hs);
+                    hs &= hs - 1ull;
+                    const float2 pj = spos_env[64 * ws + u];
+                    const float dx = xi - pj.x, dy = yi - pj.y;
+                    const bool hit = fmaf(dy, dy, dx * dx) < thr_t;
+                    left = 0ull;
+#pragma unroll
+                    for (int w = 0; w < WMAX; ++w) {
+                        if (w == ws) { pool[w] = hs; if (hit) first[w] |= 1ull << u; }
+                        left |= pool[w];
+                    }
+                }
+#pragma unroll
+                for (int w = 0; w < WMAX; ++w) pool[w] = first[w];       // the verdicts replace the candidates
+            } else {
 #pragma unroll
             for (int w = 0; w < WMAX; ++w) {
                 if (w < W) {
@@ -976,6 +1004,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     }
                     pool[w] = hits;                          // the verdicts replace the candidates
                 }
+            }
             }
             if (CACHED_B) {                                  // keep the list and where it was taken
 #pragma unroll
@@ -1523,7 +1552,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 int *const c_episode = ca.episode;
                 if (!rand_act && rs)                          // the episode counter is only needed here: read it now (past
                     epi = (uint32_t)__builtin_nontemporal_load(c_episode + env);   // L1: an earlier reset of this launch wrote it)
-                if (rs && agent == 0) c_episode[env] = (int)(epi + 1u);
+                // (the counter is stored back -- by agent 0 -- only behind the first barrier of the sampling loop, and every
+                // wave waits for its own read first: written right here, a wave that ran ahead could hand a slower wave of
+                // the same env the INCREMENTED counter, i.e. another Philox stream for its 64 agents.  Round 4: found by the
+                // rollout fuzz of tests/test_gpu_fuzz.py as a 1-in-5 flake of multi-wave envs, present since round 2.)
+                if (!WL && !rand_act) __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): epi has arrived
+                if (WL && rs && agent == 0) c_episode[env] = (int)(epi + 1u);      // (one wave per env: nobody else reads it)
                 // terminal state of the finished episode (drone_env.py:258 returns it; the reset below overwrites it)
                 float *const c_pos_final = ca.pos_final, *const c_z_final = ca.z_final;
                 int *const c_nbr_final = ca.nbr_final;
@@ -1565,6 +1599,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     // barrier above) -- clearing it right behind agent 0's own read let a late wave see 0, skip this
                     // block and miss its barriers
                     if (!SYM && round == 0 && rs && agent == 0) sred[2 * slot + 1] = 0;
+                    if (!WL && round == 0 && rs && agent == 0) c_episode[env] = (int)(epi + 1u);   // (every wave has read the old value)
                     int prop = node, h = 0;
                     if (rs) {
                         if (node < 0)

@@ -472,3 +472,36 @@ def test_reobservation_after_in_kernel_reset_matches_the_oracle(torch, N, G, E, 
     m = H.z_compare_mask(ref["nbr_idx"], np.ones((E, N), bool) if not default_delta else np.zeros((E, N), bool), c)
     H.assert_close(np.where(m, zz, 0)[safe], np.where(m, ref["z"], 0)[safe], "re-observed z", atol=H.atol_coord(G))
     assert torch.equal(env.z, z) and torch.equal(env.nbr_idx, nb)
+
+
+@pytest.mark.parametrize("N,G,E", [(1024, 1030.0, 2), (300, 300.0, 6), (130, 130.0, 16), (256, 256.0, 12)], ids=lambda v: str(v))
+def test_in_kernel_reset_of_multi_wave_envs_draws_the_oracle_state_every_time(torch, N, G, E):
+    """Envs of several waves: every wave must draw its agents' lattice nodes from the SAME episode counter.  Through
+    round 3 agent 0 stored the incremented counter while slower waves of the env could still be reading it (a 1-in-5
+    flake found by the rollout fuzz: 64 agents of an env on another Philox stream).  The state that ends the episode is
+    UNBALANCED on purpose -- the first wave's agents far from everybody (no pair work: it reaches the reset first), the
+    others crowded -- and the step is repeated: the fresh state is the oracle's draw (drone_env.py:98-102, 171-205 restated
+    in oracle_reset) and the same bits on every repetition.  (The race needed a wave to reach its read ~0.5 us late -- e.g. an
+    instruction-cache miss on the cold path -- so this test did not fail reliably on the old code; the repeated rollout fuzz
+    of tests/test_gpu_fuzz.py is the statistical guard: 5 of 6 runs failed before the fix, 0 of 8 after.)"""
+    orc = Oracle(N, [G, G], 2, np.ones(N), True, threads=4)
+    rpos, rvel, rt, rnode, repi = orc.reset(E, 99)
+    want = orc.reset(E, 99, pos=rpos.copy(), vel=rvel.copy(), t=rt.copy(), episode=repi.copy())[0]
+    rng = np.random.default_rng(1)
+    pos0 = np.empty((E, N, 2), np.float32)
+    pos0[:, :64, 0] = np.linspace(0.05 * G, 0.95 * G, 64); pos0[:, :64, 1] = 0.02 * G          # a sparse line
+    pos0[:, 64:] = (0.5 * G + (rng.random((E, N - 64, 2)) - 0.5) * min(0.05 * G, 12.0)).astype(np.float32)   # a crowd
+    act = torch.zeros(E, N, 2, device="cuda:0")
+    first = None
+    for rep in range(20):
+        env = make_env(N, G, E, seed=99, auto_reset=True)
+        env.set_state(pos0, None, np.full(E, 199, np.int32))
+        res = env.step(act)
+        torch.cuda.synchronize()
+        assert bool(res.finished.all())
+        got = host(env.pos)
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6, err_msg=f"repetition {rep}")
+        if first is None:
+            first = got
+        assert np.array_equal(got, first), (rep, int((got != first).sum()))
+        assert host(env.episode).tolist() == [2] * E
