@@ -289,6 +289,30 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def device_span(workload):
+    """The step launches as the DEVICE sees them: first wave in -> last wave out (`span_us`) and last wave out -> the next
+    launch's first wave (`boundary_us`) inside a hipGraph replay, from the waves' own entry / exit times on the chip-wide
+    100 MHz clock.  Measured in a separate process on the -DDRONESIM_TRACE_SPAN build of the same source
+    (libdronesim_span.so: product code + one s_memrealtime pair and one 8-byte store per wave; ~2 % slower), so that the
+    benchmarked process keeps the product library.  None when that build is not there."""
+    import subprocess
+    lib = os.path.join(ROOT, "scalable_collision_avoidance_rl_amd", "libdronesim_span.so")
+    if not os.path.exists(lib):
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_span.py"), workload, "64"], capture_output=True,
+                           text=True, timeout=240, env=dict(os.environ, DRONESIM_LIB=lib))
+        for line in r.stdout.splitlines():
+            if line.startswith("SPAN_JSON "):
+                d = json.loads(line[10:])
+                d["how"] = ("tools/trace_span.py on libdronesim_span.so (-DDRONESIM_TRACE_SPAN): 64 traced step launches in one "
+                            "hipGraph, medians; 10 ns clock")
+                return d
+    except (subprocess.SubprocessError, OSError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -656,6 +680,12 @@ def main():
                 except Exception as ex:                 # a side measurement must never cost the headline line
                     other[key] = {"error": f"{type(ex).__name__}: {ex}"}
             out["other_workloads"] = other
+        if world == 1 and not args.no_other_workloads and args.workload in ("c2", "c3", "c5") and policy is None and layer and not args.envs_per_gpu:
+            torch.cuda.empty_cache()
+            ds = device_span(args.workload)
+            if ds is not None:                           # bytes moved inside the launch's own execution window
+                ds["frac_inside_span"] = bytes_launch / (ds["span_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["device_clock"] = ds
         if world == 1 and not args.no_rccl_probe:
             out["exchange"]["rccl_probe"] = rccl_probe()
         print(json.dumps(out))

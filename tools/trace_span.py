@@ -60,3 +60,8 @@ print(f"  median wave out - first wave in       : {q((med_out - first_in)[1:])}"
 print(f"  gap    last wave out -> next first in : {q(gap)}")
 print(f"  period first wave in -> next first in : {q(period)}    <- the device-side cost of a step")
 print(f"  HIP events around the same replay     : {np.median(ev):.2f} us per step")
+import json
+print("SPAN_JSON " + json.dumps({"spec": spec, "episode_layer": bool(layer), "launches": L, "waves_per_launch": waves,
+                                 "span_us": float(np.median(span[1:])), "median_wave_out_us": float(np.median((med_out - first_in)[1:])),
+                                 "boundary_us": float(np.median(gap)), "period_us": float(np.median(period)),
+                                 "hip_event_us_per_step": float(np.median(ev))}))
