@@ -420,9 +420,10 @@ def main():
     torch.cuda.synchronize()
 
     # secondary figure: the same K steps launched eagerly from Python (host launch latency included)
+    eager_steps = max(args.steps, 1000) if policy is None else args.steps     # (a 20-step loop would mostly time its two syncs)
     barrier()
     t0 = time.perf_counter()
-    for s in range(args.steps):
+    for s in range(eager_steps):
         one_step(step_no); step_no += 1
     barrier()
     eager_elapsed = time.perf_counter() - t0
@@ -643,8 +644,9 @@ def main():
                          "collective_latency_us": allgather_us},
             "launch_check": launch_check,
             "episode_end_stats": summary,
-            "eager": {"value": N * E_global * args.steps / eager_elapsed, "ms_per_step": eager_elapsed / args.steps * 1e3,
-                      "note": "the same K steps launched one by one from Python (host launch latency included)"},
+            "eager": {"value": N * E_global * eager_steps / eager_elapsed, "ms_per_step": eager_elapsed / eager_steps * 1e3,
+                      "steps": eager_steps,
+                      "note": "max(K, 1000) steps launched one by one from Python, no hipGraph (host launch latency included)"},
             "fused_rollout": None if ro_us is None else {
                 "us_per_step_per_gpu": ro_us, "agent_steps_per_s_per_gpu": N * E / ro_us * 1e6,
                 "roofline_frac_52B": 52.0 * N * E / (ro_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
