@@ -1501,3 +1501,51 @@ def test_episode_statistic_kernel(torch):
     np.testing.assert_allclose(host(st.vec)[3:], [5 * E * N, 5 * E])
     from scalable_collision_avoidance_rl_amd import _native
     assert _native.lib().dronesim_episode_stats(None, None, None, 1, 1, None, None, None) == -1      # DRONESIM_EINVAL
+
+
+# ------------------------------------------------------------------------------- round 4: ADVICE r3 items on the policies
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16x2", "bf16"])
+def test_policy_weight_updates_reach_the_kernel_after_refresh(torch, prec):
+    """The kernels read PACKED images of the weights (snapshots).  After an in-place update of the live tensors the
+    outputs are stale until `refresh_weights()` re-packs -- into the SAME device buffers (a captured graph stays valid) --
+    and then equal a freshly built network's (SAC_agents.py: the actors are re-evaluated after every optimiser step)."""
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    N, E, d, h, nout = 6, 70, 6, 96, 4
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * 0.3
+    w = [r(N, d, h), r(N, h), r(N, h, h), r(N, h), r(N, h, nout), r(N, nout)]
+    pol = BatchedMLP(*w, 2, 0, device="cuda", precision=prec)                   # ("cuda" without an index is accepted)
+    x = torch.rand(E, N, d, device="cuda:0") * 2 - 1
+    out0 = pol.forward(x).clone()
+    ptrs = [getattr(pol, n).data_ptr() for n in ("_w1p", "_w2p", "_w3p") if getattr(pol, n, None) is not None]
+    w2 = [t * 1.5 + 0.01 for t in w]
+    for name, t in zip(("w1", "b1", "w2", "b2", "w3", "b3"), w2):
+        getattr(pol, name).copy_(t.to("cuda:0"))                                # an in-place update of the live tensors
+    graph_out = torch.empty_like(out0)
+    pol.refresh_weights()
+    assert ptrs == [getattr(pol, n).data_ptr() for n in ("_w1p", "_w2p", "_w3p") if getattr(pol, n, None) is not None]
+    out1 = pol.forward(x, out=graph_out)                                        # out= on device "cuda:0" with a "cuda" policy
+    ref = BatchedMLP(*w2, 2, 0, device="cuda:0", precision=prec).forward(x)
+    assert torch.equal(out1, ref) and not torch.equal(out1, out0)
+    pol.refresh_weights(w2=w[2])                                                # the keyword form copies, then re-packs
+    w3 = list(w2); w3[2] = w[2]
+    assert torch.equal(pol.forward(x), BatchedMLP(*w3, 2, 0, device="cuda:0", precision=prec).forward(x))
+
+
+def test_packed_w2_must_be_aligned(torch):
+    """DroneMlp.w2_layout = 1 is read with 16-byte vector loads: a misaligned packed array is EINVAL, not a fault."""
+    import ctypes as C
+    from scalable_collision_avoidance_rl_amd import _native
+    from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
+    g = torch.Generator().manual_seed(1)
+    r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * 0.3
+    pol = BatchedMLP(r(2, 6, 32), r(2, 32), r(2, 32, 32), r(2, 32), r(2, 32, 4), r(2, 4), 0, 0, device="cuda:0")
+    x = torch.rand(8, 2, 6, device="cuda:0"); out = torch.empty(8, 2, 4, device="cuda:0")
+    m = pol._m
+    good = m.w2
+    m.w2 = good + 4
+    rc = pol._lib.dronesim_mlp_forward(C.byref(m), x.data_ptr(), out.data_ptr(), None, None, 0, 0, 0, None, None, 8,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == _native.EINVAL and b"16-byte aligned" in pol._lib.dronesim_last_error()
+    m.w2 = good
+    assert torch.isfinite(pol.forward(x)).all()
