@@ -48,6 +48,8 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_AGENT_STEP = 76        # reads pos 8 + act 8; writes pos 8, vel 8, r 4, true_r 4, z 24, nbr 12
 BYTES_PER_ENV_STEP = 13          # n_coll 4 + done 1 + t read/write 8
 BYTES_PER_ENV_STEP_RECORD = 64   # episode layer: the hot 32 bytes of the env's DroneEpisodeAcc record, read + written
+GRAPH_LAUNCHES = int(os.environ.get("BENCH_GRAPH_LAUNCHES", "4000"))   # launches captured into the one replayed graph
+#                                  (profiles/r4_graph_size_probe.log: 2000 -> 5.20 us/step, 4000 -> 5.14, 16000 -> 5.31)
 
 WORKLOADS = {
     #        N    E/GPU  G      Delta  label
@@ -442,7 +444,7 @@ def main():
         # with 250 launches per graph, 5.73 with 1000, 5.62 with 4000): the request is captured several times over into
         # ONE graph of ~4000 launches (the episode layer keeps every counter on the device, so the copies simply
         # continue the rollout), and the per-step figure of `--steps 20` is that of `--steps 2000`
-        copies = max(1, -(-4000 // K)) if layer else 1
+        copies = max(1, -(-GRAPH_LAUNCHES // K)) if layer else 1
         L = K * copies
         # the exchange's local half at the reference's cadence, INSIDE the capture: after every T_ep-th launch one
         # fixed-order reduction of the episode records (train_problem.py:118-121 logs once per episode) into its own
