@@ -296,9 +296,40 @@ __device__ __forceinline__ void tile_gemm_packed(f32x16 &acc, const float *Arow,
     }
 }
 
+// ---- layer 3 of a chunk for nout <= 16 (every network of the reference: 16 action probabilities, 4 Gaussian moments, 1
+// value) on v_mfma_f32_16x16x4_f32.  The 32x32x2 form spends 16 matrix instructions of 64 cycles per chunk on 32 output
+// columns of which at most 16 exist (8 % of the kernel's matrix time at h = 400); two 16-row tiles x 8 k-steps of the
+// 16-column instruction are 16 x 32 cycles.  Lane (i = lane & 15, g = lane >> 4) feeds k-step ks with k = 8 g + ks (any
+// assignment of the chunk's 32 k values to (g, ks) is a valid contraction order; this one makes a lane's eight A values
+// CONSECUTIVE floats of its staged row: two ds_read_b128 per tile instead of eight ds_read_b32; kStN = 36 floats per
+// row = a multiple of 4 with an odd quotient, so the 8 lanes of a read phase hit different bank quads) and reads its
+// eight W3 values once for both tiles.  D: reg r of lane l = (row 4 (l >> 4) + r, col l & 15).
+constexpr int kStW = 33, kStN = 36;      // floats per row of the per-wave staging tile (wide / narrow layer 3)
+
+__device__ __forceinline__ void layer3_narrow(f32x4 (&y)[2], const float *st, const float *__restrict__ w3c, int nout, int kvalid, int lane)
+{
+    const int g = lane >> 4, i = lane & 15, c = min(i, nout - 1);
+    float b[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int k = 8 * g + ks;
+        const float w = w3c[(size_t)min(k, kvalid - 1) * nout + c];                 // clamped address, masked value
+        b[ks] = k < kvalid ? w : 0.0f;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const f32x4 *ap = reinterpret_cast<const f32x4 *>(st + (mt * 16 + i) * kStN + 8 * g);
+        const f32x4 a0 = ap[0], a1 = ap[1];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], b[ks], y[mt], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) y[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], b[4 + ks], y[mt], 0, 0, 0);
+    }
+}
+
 // kRows env rows of one agent per workgroup, 4 waves per 32-row tile: wave w owns feature chunks (w & 3),
 // (w & 3) + 4, ... of the rows of tile (w >> 2).
-template <bool PACKED>                   // PACKED: W2 in the fragment layout of tile_gemm_packed
+template <bool PACKED, bool NARROW>      // PACKED: W2 in the fragment layout of tile_gemm_packed; NARROW: nout <= 16
 __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, int N, int d_in, const MArgs rest)
 {
     MArgs a = rest;                      // leading scalars are preloaded into SGPRs at wave launch (csrc/Makefile)
@@ -315,7 +346,8 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     const int ldx = a.d_in + 1, ld1 = PACKED ? packed_row_stride(a.h1) : a.h1 + 1;
     float *sx = reinterpret_cast<float *>(smem);                 // [rows][d_in+1]
     float *sh1 = sx + kRows * ldx;                               // [rows][h1+1]
-    float *sst = sh1 + kRows * ld1;                              // [waves][32][33] layer-2 chunk staging,
+    constexpr int kSt = NARROW ? kStN : kStW;
+    float *sst = sh1 + kRows * ld1;                              // [waves][32][kSt] layer-2 chunk staging,
                                                                  // reused for the layer-3 partials
     const float *w1 = a.w1 + (size_t)agent * a.d_in * a.h1, *b1 = a.b1 + (size_t)agent * a.h1;
     const int nst = (a.h1 + 15) >> 4;                            // PACKED: 16-k stages of layer 2
@@ -407,7 +439,8 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     // pipe 54 % busy).  So only whole rounds of four chunks are dealt; every LEFTOVER chunk is split over the four waves
     // by K (each wave a quarter of the h1 range), the partial tiles meet in LDS and one wave finishes the chunk.
     f32x16 y = {0};
-    float *st = sst + wave * 32 * 33;
+    f32x4 yn[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    float *st = sst + wave * 32 * kSt;
     const int nch = (a.h2 + 31) >> 5;
     // ... when exactly ONE chunk is left over (13 chunks at h = 400: measured -5.5 % at the C5 shard, -4.3 % at C3); with two
     // or three leftover chunks (h = 300, h = 200) the two barriers and the serial finish per chunk cost more than the
@@ -435,18 +468,18 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
         bool l3 = true;                                          // this wave feeds the chunk to layer 3
         if (!left) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = ok ? fmaxf(acc[r] + bias, 0.0f) : 0.0f;
+            for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * kSt + col] = ok ? fmaxf(acc[r] + bias, 0.0f) : 0.0f;
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = acc[r];      // this wave's partial tile
+            for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * kSt + col] = acc[r];     // this wave's partial tile
             __syncthreads();
             l3 = cw == ((it - rounds) & 3);                      // one wave adds the four partials in a fixed order
             if (l3) {
-                const float *p0 = sst + (rh * 4) * 32 * 33;
+                const float *p0 = sst + (rh * 4) * 32 * kSt;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int o = cd_row(r, lane) * 33 + col;
-                    const float v = ((p0[o] + p0[32 * 33 + o]) + p0[2 * 32 * 33 + o]) + p0[3 * 32 * 33 + o];
+                    const int o = cd_row(r, lane) * kSt + col;
+                    const float v = ((p0[o] + p0[32 * kSt + o]) + p0[2 * 32 * kSt + o]) + p0[3 * 32 * kSt + o];
                     st[o] = ok ? fmaxf(v + bias, 0.0f) : 0.0f;
                 }
             }
@@ -454,14 +487,24 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (l3) tile_gemm(y, st, 33, w3 + (size_t)c0 * a.nout, a.nout, min(32, a.h2 - c0), a.nout, lane);
+        if (l3) {
+            if (NARROW) layer3_narrow(yn, st, w3 + (size_t)c0 * a.nout, a.nout, min(32, a.h2 - c0), lane);
+            else tile_gemm(y, st, kStW, w3 + (size_t)c0 * a.nout, a.nout, min(32, a.h2 - c0), a.nout, lane);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (left) __syncthreads();                               // the partial regions are free again
     }
     PT(4);
+    if (NARROW) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * 33 + col] = y[r];   // this wave's partial outputs
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[(mt * 16 + 4 * (lane >> 4) + r) * kSt + (lane & 15)] = yn[mt][r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * kSt + col] = y[r];   // this wave's partial outputs
+    }
     __syncthreads();
     PT(5);
 
@@ -479,7 +522,7 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
             if (j < a.nout) {
                 v = b3v[i];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += sst[((rhh * 4 + w) * 32 + rr) * 33 + j];
+                for (int w = 0; w < 4; ++w) v += sst[((rhh * 4 + w) * 32 + rr) * kSt + j];
             }
             yv[i] = v;
         }
@@ -1313,18 +1356,20 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     const bool packed = m->w2_layout == 1;
     const size_t ld1 = packed ? (size_t)packed_row_stride(m->h1) : (size_t)m->h1 + 1;
     // (x rows: d_in + 1 floats; the h1 tile follows on a 16-byte boundary)
-    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * ld1 + (kThreadsF / 64) * 32 * 33);
+    const bool narrow = m->nout <= 16;                           // layer 3 on the 16-column matrix instruction
+    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * ld1 + (kThreadsF / 64) * 32 * (narrow ? kStN : kStW));
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
+    typedef void (*Kernel)(const float *, int, int, int, const MArgs);
+    static const Kernel kernels[2][2] = {{mlp3_kernel<false, false>, mlp3_kernel<false, true>}, {mlp3_kernel<true, false>, mlp3_kernel<true, true>}};
+    const Kernel kernel = kernels[packed ? 1 : 0][narrow ? 1 : 0];
     {
         static std::mutex mu;
-        static unsigned long long opted[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}};
-        const int lrc = enable_big_lds(packed ? reinterpret_cast<const void *>(mlp3_kernel<true>) : reinterpret_cast<const void *>(mlp3_kernel<false>),
-                                       opted[packed ? 1 : 0], mu, "mlp3_kernel");
+        static unsigned long long opted[4][4] = {};
+        const int lrc = enable_big_lds(reinterpret_cast<const void *>(kernel), opted[(packed ? 2 : 0) + (narrow ? 1 : 0)], mu, "mlp3_kernel");
         if (lrc) return lrc;
     }
     const dim3 grid(((E + kRows - 1) / kRows) * m->N);
-    if (packed) hipLaunchKernelGGL(mlp3_kernel<true>, grid, dim3(kThreadsF), lds, static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
-    else hipLaunchKernelGGL(mlp3_kernel<false>, grid, dim3(kThreadsF), lds, static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
+    hipLaunchKernelGGL(kernel, grid, dim3(kThreadsF), lds, static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;
