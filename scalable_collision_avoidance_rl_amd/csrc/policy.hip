@@ -436,26 +436,32 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     // ---- layers 2 + 3 fused over this wave's column chunks.  The chunk count is rarely a multiple of four (13 at
     // h = 400, 10 at h = 300, 7 at h = 200): dealt whole, one wave gets a chunk more than the others, runs 4 : 3 longer and
     // the other three wait for it holding their slots (round 3 trace: 140k against 110-116k cycles per wave, the matrix
-    // pipe 54 % busy).  So only whole rounds of four chunks are dealt; every LEFTOVER chunk is split over the four waves
-    // by K (each wave a quarter of the h1 range), the partial tiles meet in LDS and one wave finishes the chunk.
+    // pipe 54 % busy).  So only whole rounds of four chunks are dealt, and the leftover chunks are SPLIT BY K in one more
+    // trip: one leftover chunk over the four waves (a quarter of the h1 range each), two leftover chunks over two pairs of
+    // waves (half the range each); the partial tiles meet in LDS and one wave per chunk finishes it.
     f32x16 y = {0};
     f32x4 yn[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
     float *st = sst + wave * 32 * kSt;
     const int nch = (a.h2 + 31) >> 5;
-    // ... when exactly ONE chunk is left over (13 chunks at h = 400: measured -5.5 % at the C5 shard, -4.3 % at C3); with two
-    // or three leftover chunks (h = 300, h = 200) the two barriers and the serial finish per chunk cost more than the
-    // balance gains (+1.5 % / +19 %), so those deal their chunks whole as before
-    const int nch_even = (nch & 3) == 1 ? (nch & ~3) : nch;
+    // Measured at the C5 shard: one leftover (13 chunks at h = 400) -5.5 %, -4.3 % at C3; two leftovers (10 chunks at h = 300)
+    // as pairs -8.7 % (round 4; as two quarter-split trips, i.e. four barriers, +1.5 %); three leftovers (7 chunks at
+    // h = 200) lose either way (three quarter-split trips +19 %, a pair trip + a quarter trip +4 %) and are dealt whole
+    const int rem = (nch & 3) == 3 ? 0 : (nch & 3);              // leftover chunks that are split (3: dealt whole)
+    const int nch_even = rem ? (nch & ~3) : nch;
+    const int split = rem == 2 ? 2 : 4;                          // waves sharing a leftover chunk
+    const int ntrips = rem ? 1 : 0;
     // ONE loop over both kinds of trips (one inlined copy of each GEMM: a second copy of the layer-2 loop took the kernel
     // from 244 to 272 registers, i.e. from two workgroups per CU to one): first the whole rounds, then the leftover chunks
     const int rounds = (nch_even + 3) >> 2;                      // (whole dealing: the last round may be ragged)
-    const int kq = PACKED ? 16 * ((nst + 3) >> 2) : (((a.h1 + 3) >> 2) + 1) & ~1;   // a quarter of K (even; PACKED: whole stages)
     const int kpad = PACKED ? 16 * nst : a.h1;
-    for (int it = 0; it < rounds + (nch - nch_even); ++it) {     // wave-uniform trip count (barriers inside)
-        const bool left = it >= rounds;                          // leftover chunk: this wave's K quarter of it
-        const int c0 = (left ? nch_even + (it - rounds) : cw + 4 * it) * 32;
+    for (int it = 0; it < rounds + ntrips; ++it) {               // wave-uniform trip count (barriers inside)
+        const bool left = it >= rounds;                          // leftover trip: this wave's K part of a leftover chunk
+        const int part = cw & (split - 1);                       // this wave's K part
+        const int lch = nch_even + (rem == 2 ? cw >> 1 : 0);
+        const int c0 = (left ? lch : cw + 4 * it) * 32;
         if (!left && c0 >= nch_even * 32) continue;              // ragged last round of the whole dealing (no barrier in it)
-        const int kb = left ? min(cw * kq, kpad) : 0, kn = left ? min(kq, kpad - kb) : kpad;
+        const int kq = PACKED ? 16 * ((nst + split - 1) / split) : (((a.h1 + split - 1) / split) + 1) & ~1;   // 1/split of K (even; PACKED: whole stages)
+        const int kb = left ? min(part * kq, kpad) : 0, kn = left ? min(kq, kpad - kb) : kpad;
         const bool ok = c0 + col < a.h2;
         const float bias = ok ? b2[c0 + col] : 0.0f;             // issued before the k-loop, needed after it
         f32x16 acc = {0};
@@ -473,13 +479,13 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * kSt + col] = acc[r];     // this wave's partial tile
             __syncthreads();
-            l3 = cw == ((it - rounds) & 3);                      // one wave adds the four partials in a fixed order
+            l3 = part == 0;                                      // one wave per chunk adds the partials in a fixed order
             if (l3) {
-                const float *p0 = sst + (rh * 4) * 32 * kSt;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = cd_row(r, lane) * kSt + col;
-                    const float v = ((p0[o] + p0[32 * kSt + o]) + p0[2 * 32 * kSt + o]) + p0[3 * 32 * kSt + o];
+                    float v = st[o] + st[32 * kSt + o];
+                    if (split == 4) v = (v + st[2 * 32 * kSt + o]) + st[3 * 32 * kSt + o];
                     st[o] = ok ? fmaxf(v + bias, 0.0f) : 0.0f;
                 }
             }
