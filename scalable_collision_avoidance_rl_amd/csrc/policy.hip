@@ -257,21 +257,46 @@ __device__ __forceinline__ void load_set(FragSet &t, const float *Arow, const f3
     t.b0 = bp[0]; t.b1 = bp[64];
     t.a0 = ap[0]; t.a1 = ap[1];
 }
+template <bool TR>                        // TR: the transposed product D^T[feature][row] (the weights as the A operand)
 __device__ __forceinline__ void mfma_set(f32x16 &acc, const FragSet &t)
 {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.a0[u], t.b0[u], acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(TR ? t.b0[u] : t.a0[u], TR ? t.a0[u] : t.b0[u], acc, 0, 0, 0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.a1[u], t.b1[u], acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(TR ? t.b1[u] : t.a1[u], TR ? t.a1[u] : t.b1[u], acc, 0, 0, 0);
+}
+
+// Transposed tiles (TR).  D[i][j] of v_mfma_f32_32x32x2_f32 puts FOUR CONSECUTIVE i (registers 4 q .. 4 q + 3 = rows
+// 8 q + 4 (lane >> 5) + 0..3) of column j = lane & 31 into a lane.  With the weights as the A operand i is the feature and
+// j the env row, so a lane's registers are contiguous pieces of its row of the next layer's input: the relu'd tile goes
+// to LDS as four ds_write_b128 instead of sixteen ds_write_b32, and the bias -- one value per feature, i.e. per A row
+// -- rides on one more matrix instruction (A = bias in the k slot of lanes 0..31, B = 1 there, 0 in the other k slot:
+// fmaf(bias, 1, acc), rounded exactly like acc + bias) instead of sixteen v_add.  Per 32 x 32 tile: 16 v_max + 4 wide
+// writes instead of 16 x (v_add, v_max, ds_write_b32).  Every instruction saved here is an issue slot the OTHER
+// workgroup's wave on the SIMD gets for its matrix stream (the float32 matrix instructions run on the vector ALUs).
+__device__ __forceinline__ f32x16 bias_mfma(f32x16 acc, float bias, int lane)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(lane < 32 ? bias : 0.0f, lane < 32 ? 1.0f : 0.0f, acc, 0, 0, 0);
+}
+template <bool RELU>
+__device__ __forceinline__ void store_tile_tr(float *rowp, const f32x16 &acc, int lane)     // rowp: this lane's row + chunk offset
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = RELU ? fmaxf(acc[4 * q + t], 0.0f) : acc[4 * q + t];
+        *reinterpret_cast<f32x4 *>(rowp + 8 * q + 4 * (lane >> 5)) = v;
+    }
 }
 
 // acc += (h1 tile, stages [sb, sb + n)) x (packed chunk).  Arow: this lane's LDS row + 8 half; Bp: chunk base + lane.
-template <int R>
+template <int R, bool TR>
 __device__ __forceinline__ void tile_gemm_packed(f32x16 &acc, const float *Arow, const f32x4 *Bp, int sb, int n)
 {
     FragSet set[R];
     if (n < R - 1) {                                         // (a hidden layer of <= 16 (R - 2) units)
-        for (int s1 = 0; s1 < n; ++s1) { load_set(set[0], Arow, Bp, sb + s1); mfma_set(acc, set[0]); }
+        for (int s1 = 0; s1 < n; ++s1) { load_set(set[0], Arow, Bp, sb + s1); mfma_set<TR>(acc, set[0]); }
         return;
     }
 #pragma unroll
@@ -283,7 +308,7 @@ __device__ __forceinline__ void tile_gemm_packed(f32x16 &acc, const float *Arow,
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             load_set(set[(r + R - 1) % R], Arow, Bp, sb + s + r + R - 1);
-            mfma_set(acc, set[r]);
+            mfma_set<TR>(acc, set[r]);
         }
     }
     // the last <= 2 R - 2 stages
@@ -291,7 +316,7 @@ __device__ __forceinline__ void tile_gemm_packed(f32x16 &acc, const float *Arow,
     for (int r = 0; r < 2 * R - 2; ++r) {
         if (s + r < n) {                                     // wave-uniform
             if (s + r + R - 1 < n) load_set(set[(r + R - 1) % R], Arow, Bp, sb + s + r + R - 1);
-            mfma_set(acc, set[r % R]);
+            mfma_set<TR>(acc, set[r % R]);
         }
     }
 }
@@ -347,6 +372,7 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     float *sx = reinterpret_cast<float *>(smem);                 // [rows][d_in+1]
     float *sh1 = sx + kRows * ldx;                               // [rows][h1+1]
     constexpr int kSt = NARROW ? kStN : kStW;
+    constexpr bool TR = PACKED && NARROW;                        // transposed tiles (see store_tile_tr)
     float *sst = sh1 + kRows * ld1;                              // [waves][32][kSt] layer-2 chunk staging,
                                                                  // reused for the layer-3 partials
     const float *w1 = a.w1 + (size_t)agent * a.d_in * a.h1, *b1 = a.b1 + (size_t)agent * a.h1;
@@ -356,6 +382,7 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     const float *w3 = a.w3 + (size_t)agent * a.h2 * a.nout, *b3 = a.b3 + (size_t)agent * a.nout;
 
     PT(0);
+    const unsigned long long rt0 = kTrace ? __builtin_amdgcn_s_memrealtime() : 0ull;   // trace builds: 100 MHz clock at entry
     // ---- x tile -> LDS (rows beyond E are zero)
     for (int idx = tid; idx < kRows * a.d_in; idx += kThreadsF) {
         const int r = idx / a.d_in, c = idx - r * a.d_in;
@@ -390,6 +417,15 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
             const int c0 = cw * 32 + 128 * i;
             if (c0 < a.h1) {
                 f32x16 acc = {0};
+                if (TR) {
+                    const bool ok = c0 + col < a.h1;             // features beyond h1 (the k padding of layer 2) come out as zero
+#pragma unroll
+                    for (int u = 0; u < kU; ++u)
+                        if (2 * u < a.d_in) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? f[i].b[u] : 0.0f, f[i].a[u], acc, 0, 0, 0);
+                    acc = bias_mfma(acc, bias[i], lane);
+                    store_tile_tr<true>(sh1 + (rh * 32 + col) * ld1 + c0, acc, lane);
+                    continue;
+                }
 #pragma unroll
                 for (int u = 0; u < kU; ++u)
                     if (2 * u < a.d_in) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].a[u], f[i].b[u], acc, 0, 0, 0);
@@ -467,12 +503,31 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
         f32x16 acc = {0};
         if (PACKED) {
             if (kn > 0)
-                tile_gemm_packed<POLICY_SETS>(acc, sh1 + (rh * 32 + col) * ld1 + 8 * (lane >> 5),
+                tile_gemm_packed<POLICY_SETS, TR>(acc, sh1 + (rh * 32 + col) * ld1 + 8 * (lane >> 5),
                                     reinterpret_cast<const f32x4 *>(w2 + (size_t)(c0 >> 5) * nst * 512) + lane, kb >> 4, kn >> 4);
         } else if (kn > 0)
             tile_gemm(acc, sh1 + rh * 32 * ld1 + kb, ld1, w2 + c0 + (size_t)kb * a.h2, a.h2, kn, a.h2 - c0, lane);
         bool l3 = true;                                          // this wave feeds the chunk to layer 3
-        if (!left) {
+        if (TR) {                                                // (packed W2 and the masked bias are zero beyond h2)
+            if (!left || part == 0) acc = bias_mfma(acc, bias, lane);
+            if (!left) store_tile_tr<true>(st + col * kSt, acc, lane);
+            else {
+                store_tile_tr<false>(st + col * kSt, acc, lane);                     // this wave's partial tile (part 0: + bias)
+                __syncthreads();
+                l3 = part == 0;                                  // one wave per chunk adds the partials in a fixed order
+                if (l3) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 *p = reinterpret_cast<f32x4 *>(st + col * kSt + 8 * q + 4 * (lane >> 5));
+                        f32x4 v = p[0] + p[32 * kSt / 4];
+                        if (split == 4) v = (v + p[2 * 32 * kSt / 4]) + p[3 * 32 * kSt / 4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
+                        p[0] = v;
+                    }
+                }
+            }
+        } else if (!left) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[cd_row(r, lane) * kSt + col] = ok ? fmaxf(acc[r] + bias, 0.0f) : 0.0f;
         } else {
@@ -513,6 +568,8 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     }
     __syncthreads();
     PT(5);
+    if (kTrace && a.trace && lane == 0 && wave >= 2)             // (slot 6 of waves 2, 3 is free: the finish stamp is waves 0, 1)
+        a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 6] = (long long)(__builtin_amdgcn_s_memrealtime() - rt0);
 
     // ---- output activation + sampling: four lanes per env row
     if (tid < 4 * kRows) {

@@ -36,6 +36,8 @@ lib.dronesim_debug_set_policy_trace(None)
 t = trace.cpu().numpy().astype(np.float64)
 names = ["entry", "prologue + barrier", "layer 1 done", "barrier", "h1 tile in registers", "layers 2+3 done",
          "partials + barriers", "finish"]
+if prec == "f32":
+    names = ["entry", "x tile + barrier", "layer 1 done", "barrier", "layers 2+3 done", "partials + barrier", "finish"]
 print(f"{kind} {spec} {shape}: {blocks} workgroups, event time {e0.elapsed_time(e1)*1e3:.1f} us; ticks ~ 100 MHz or core clock, see ratio")
 last = 6 if prec == "bf16" else 5
 life = t[:, :, last] - t[:, :, 0]
@@ -48,7 +50,14 @@ if prec == "f32":                                   # stamp 7: layer 1's operand
     d = (t[:, :, 7] - t[:, :, 1])[t[:, :, 7] > 0]
     if d.size:
         print(f"  {'of layer 1: operand wait':>24}: median {np.median(d):8.0f}  p95 {np.percentile(d, 95):8.0f}")
-d = (t[:, :, last + 1] - t[:, :, last])[t[:, :, last + 1] > 0]
+if prec == "f32":                                   # waves 2, 3: slot 6 = the wave's lifetime on the 100 MHz clock
+    d = (t[:, :2, last + 1] - t[:, :2, last])[t[:, :2, last + 1] > 0]
+    rt = t[:, 2:, 6]
+    mhz = (t[:, 2:, 5] - t[:, 2:, 0])[rt > 0] / rt[rt > 0] * 100.0
+    print(f"  shader clock over the waves' lifetimes: median {np.median(mhz):.0f} MHz  p5 {np.percentile(mhz, 5):.0f}  p95 {np.percentile(mhz, 95):.0f}"
+          f"   (lifetime median {np.median(rt[rt > 0]) / 100.0:.1f} us)")
+else:
+    d = (t[:, :, last + 1] - t[:, :, last])[t[:, :, last + 1] > 0]
 print(f"  {names[last + 1]:>24}: median {np.median(d):8.0f}  p95 {np.percentile(d, 95):8.0f}")
 span = t.max() - t[:, :, 0].min()
 print(f"  kernel span {span:.0f} ticks -> {span / (e0.elapsed_time(e1) * 1e3):.1f} ticks/us")
