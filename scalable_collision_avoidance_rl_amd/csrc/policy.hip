@@ -354,7 +354,10 @@ __device__ __forceinline__ void layer3_narrow(f32x4 (&y)[2], const float *st, co
 
 // kRows env rows of one agent per workgroup, 4 waves per 32-row tile: wave w owns feature chunks (w & 3),
 // (w & 3) + 4, ... of the rows of tile (w >> 2).
-template <bool PACKED, bool NARROW>      // PACKED: W2 in the fragment layout of tile_gemm_packed; NARROW: nout <= 16
+// NU: k-steps (of 2) of layer 1 that are loaded and issued when d_in <= 16 (3 for the reference's simplified observation,
+// d_in = 6; compile-time so that the loads stay unconditional -- wave-uniform `if (u < nu)` around them was measured +2 %:
+// hipcc drains the loads at every join)
+template <bool PACKED, bool NARROW, int NU = kU>      // PACKED: W2 in the fragment layout of tile_gemm_packed; NARROW: nout <= 16
 __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, int N, int d_in, const MArgs rest)
 {
     MArgs a = rest;                      // leading scalars are preloaded into SGPRs at wave launch (csrc/Makefile)
@@ -398,15 +401,27 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
     if (a.d_in <= 2 * kU) {
         constexpr int kL1 = 4;
         const float *Arow = sx + (rh * 32 + (lane & 31)) * ldx;
-        Frag f[kL1];
+        float wb[kL1][NU], xa[NU];                               // the x operand is the same for every chunk
         float bias[kL1];
 #pragma unroll
         for (int i = 0; i < kL1; ++i) {
             const int c0 = cw * 32 + 128 * i;
             if (c0 < a.h1) {                                     // wave-uniform
-                load_frag<true>(f[i], Arow, w1 + c0 + min(col, a.h1 - c0 - 1), a.h1, lane >> 5, a.d_in);
+                const float *Bcol = w1 + c0 + min(col, a.h1 - c0 - 1);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const int k = (lane >> 5) + 2 * u;
+                    const float w = Bcol[(size_t)min(k, a.d_in - 1) * a.h1];           // clamped address, masked value
+                    wb[i][u] = k < a.d_in ? w : 0.0f;
+                }
                 bias[i] = c0 + col < a.h1 ? b1[c0 + col] : 0.0f;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int k = (lane >> 5) + 2 * u;
+            const float v = Arow[min(k, a.d_in - 1)];
+            xa[u] = k < a.d_in ? v : 0.0f;
         }
         if (kTrace) {
             __builtin_amdgcn_s_waitcnt(0x0070);                  // trace builds: stamp 7 = layer 1's operands have arrived
@@ -420,15 +435,15 @@ __global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, 
                 if (TR) {
                     const bool ok = c0 + col < a.h1;             // features beyond h1 (the k padding of layer 2) come out as zero
 #pragma unroll
-                    for (int u = 0; u < kU; ++u)
-                        if (2 * u < a.d_in) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? f[i].b[u] : 0.0f, f[i].a[u], acc, 0, 0, 0);
+                    for (int u = 0; u < NU; ++u)
+                        if (2 * u < a.d_in) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok ? wb[i][u] : 0.0f, xa[u], acc, 0, 0, 0);
                     acc = bias_mfma(acc, bias[i], lane);
                     store_tile_tr<true>(sh1 + (rh * 32 + col) * ld1 + c0, acc, lane);
                     continue;
                 }
 #pragma unroll
-                for (int u = 0; u < kU; ++u)
-                    if (2 * u < a.d_in) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[i].a[u], f[i].b[u], acc, 0, 0, 0);
+                for (int u = 0; u < NU; ++u)
+                    if (2 * u < a.d_in) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[u], wb[i][u], acc, 0, 0, 0);
                 if (c0 + col < a.h1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -1423,12 +1438,14 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * ld1 + (kThreadsF / 64) * 32 * (narrow ? kStN : kStW));
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
     typedef void (*Kernel)(const float *, int, int, int, const MArgs);
-    static const Kernel kernels[2][2] = {{mlp3_kernel<false, false>, mlp3_kernel<false, true>}, {mlp3_kernel<true, false>, mlp3_kernel<true, true>}};
-    const Kernel kernel = kernels[packed ? 1 : 0][narrow ? 1 : 0];
+    static const Kernel kernels[5] = {mlp3_kernel<false, false>, mlp3_kernel<false, true>, mlp3_kernel<true, false>, mlp3_kernel<true, true>,
+                                      mlp3_kernel<true, true, 3>};
+    const int which = (packed && narrow && m->d_in <= 6) ? 4 : (packed ? 2 : 0) + (narrow ? 1 : 0);
+    const Kernel kernel = kernels[which];
     {
         static std::mutex mu;
-        static unsigned long long opted[4][4] = {};
-        const int lrc = enable_big_lds(reinterpret_cast<const void *>(kernel), opted[(packed ? 2 : 0) + (narrow ? 1 : 0)], mu, "mlp3_kernel");
+        static unsigned long long opted[5][4] = {};
+        const int lrc = enable_big_lds(reinterpret_cast<const void *>(kernel), opted[which], mu, "mlp3_kernel");
         if (lrc) return lrc;
     }
     const dim3 grid(((E + kRows - 1) / kRows) * m->N);
