@@ -358,7 +358,7 @@ __device__ __forceinline__ void layer3_narrow(f32x4 (&y)[2], const float *st, co
 // d_in = 6; compile-time so that the loads stay unconditional -- wave-uniform `if (u < nu)` around them was measured +2 %:
 // hipcc drains the loads at every join)
 template <bool PACKED, bool NARROW, int NU = kU>      // PACKED: W2 in the fragment layout of tile_gemm_packed; NARROW: nout <= 16
-__global__ void __launch_bounds__(kThreadsF) mlp3_kernel(const float *x, int E, int N, int d_in, const MArgs rest)
+__global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int E, int N, int d_in, const MArgs rest)
 {
     MArgs a = rest;                      // leading scalars are preloaded into SGPRs at wave launch (csrc/Makefile)
     a.x = x; a.E = E; a.N = N; a.d_in = d_in;
