@@ -969,7 +969,7 @@ def test_policy_shape_fuzz_all_precisions(torch):
     rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 7)))
     g = torch.Generator().manual_seed(int(os.environ.get("FUZZ_SEED", 7)))
     r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1)
-    for it in range(int(os.environ.get("FUZZ_ITERS", 12))):
+    for it in range(int(os.environ.get("FUZZ_ITERS", 48))):
         d = int(rng.integers(1, 17)); N = int(rng.integers(1, 7)); E = int(rng.choice([1, 2, 31, 63, 64, 65, 130, 257]))
         h1 = int(rng.choice([1, 5, 31, 32, 33, 64, 96, 100, 128, 200, 257, 400, 512]))
         h2 = int(rng.choice([1, 7, 32, 33, 64, 65, 96, 127, 128, 129, 300, 416, 480, 512]))
