@@ -17,11 +17,14 @@
 //   wave w owns every fourth 32-column chunk of the hidden layers (one 32x32 accumulator tile).
 //   32 rows keep the workgroup at ~57 KiB of LDS, so two workgroups share a CU and one's prologue, barriers
 //   and output stage overlap the other's MFMAs (64-row workgroups -- one per CU -- measured 6-12 % slower).
-//   layer 1: A = x tile (LDS), B = W1 (global/L2)            -> h1 tile in LDS [32][h1+1]
-//   layer 2 chunk (32 columns): A = h1 (LDS), B = W2          -> relu -> per-wave LDS staging [32][33]
-//   layer 3 partial: A = staged chunk, B = W3 rows of the chunk -> accumulated in registers
+//   layer 1: x tile (LDS) x W1 (global/L2)                   -> relu -> h1 tile in LDS [32][ld1]
+//   layer 2 chunk (32 columns): h1 (LDS) x W2 (fragment-packed, L2) -> relu -> per-wave LDS staging [32][36]
+//   layer 3 partial: staged chunk x W3 rows of the chunk (v_mfma_f32_16x16x4_f32 when nout <= 16) -> registers
 //   the four waves' partials are summed through LDS, then activation + sampling.
-// LDS row strides are odd (h1+1, 33) so the 32-row fragment reads are bank-conflict free.
+// With packed W2 and nout <= 16 (what the host class passes for every network of the reference) layers 1 and 2 are
+// computed transposed -- weights as the A operand -- so that tiles leave the accumulators as 16-byte row pieces
+// (store_tile_tr); the plain-layout path (w2_layout = 0, or nout > 16) keeps the row-major tiles and odd LDS strides
+// (h1 + 1, 33) of rounds 2-3.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
