@@ -408,17 +408,18 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
         float bias[kL1];
 #pragma unroll
         for (int i = 0; i < kL1; ++i) {
-            const int c0 = cw * 32 + 128 * i;
-            if (c0 < a.h1) {                                     // wave-uniform
-                const float *Bcol = w1 + c0 + min(col, a.h1 - c0 - 1);
+            // no branch around these loads, not even the wave-uniform `chunk exists`: hipcc drains the loads of a
+            // conditional block at its join (s_waitcnt vmcnt(0) per chunk: four round trips in series, 10k cycles of a wave's
+            // 100k); a chunk that does not exist re-reads the last column and is never used
+            const int c0 = cw * 32 + 128 * i, cc = min(c0 + col, a.h1 - 1);
 #pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const int k = (lane >> 5) + 2 * u;
-                    const float w = Bcol[(size_t)min(k, a.d_in - 1) * a.h1];           // clamped address, masked value
-                    wb[i][u] = k < a.d_in ? w : 0.0f;
-                }
-                bias[i] = c0 + col < a.h1 ? b1[c0 + col] : 0.0f;
+            for (int u = 0; u < NU; ++u) {
+                const int k = (lane >> 5) + 2 * u;
+                const float w = w1[(size_t)min(k, a.d_in - 1) * a.h1 + cc];            // clamped address, masked value
+                wb[i][u] = k < a.d_in ? w : 0.0f;
             }
+            const float bv = b1[cc];
+            bias[i] = c0 + col < a.h1 ? bv : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
