@@ -389,6 +389,27 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
 
     PT(0);
     const unsigned long long rt0 = kTrace ? __builtin_amdgcn_s_memrealtime() : 0ull;   // trace builds: 100 MHz clock at entry
+    const int col = lane & 31;
+    constexpr int kL1 = 4;
+    float wb[kL1][NU], bias[kL1];
+    const bool small_k = NU < kU || a.d_in <= 2 * kU;            // (the NU = 3 instance is only launched with d_in <= 6)
+    if (small_k) {                                               // layer 1's weights travel together with the x tile
+#pragma unroll
+    for (int i = 0; i < kL1; ++i) {
+        // no branch around these loads, not even the wave-uniform `chunk exists`: hipcc drains the loads of a
+        // conditional block at its join (s_waitcnt vmcnt(0) per chunk: four round trips in series, 10k cycles of a wave's
+        // 100k); a chunk that does not exist re-reads the last column and is never used
+        const int c0 = cw * 32 + 128 * i, cc = min(c0 + col, a.h1 - 1);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int k = (lane >> 5) + 2 * u;
+            const float w = w1[(size_t)min(k, a.d_in - 1) * a.h1 + cc];            // clamped address, masked value
+            wb[i][u] = k < a.d_in ? w : 0.0f;
+        }
+        const float bv = b1[cc];
+        bias[i] = c0 + col < a.h1 ? bv : 0.0f;
+    }
+    }
     // ---- x tile -> LDS (rows beyond E are zero)
     for (int idx = tid; idx < kRows * a.d_in; idx += kThreadsF) {
         const int r = idx / a.d_in, c = idx - r * a.d_in;
@@ -398,29 +419,11 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
     __syncthreads();
     PT(1);
 
-    const int col = lane & 31;
     // ---- layer 1: K = d_in is tiny, so the operands of ALL of this wave's chunks (<= 4: h1 <= 512) and their
     //      biases are requested together -- one global round trip for the layer instead of two per chunk
-    if (a.d_in <= 2 * kU) {
-        constexpr int kL1 = 4;
+    if (small_k) {
         const float *Arow = sx + (rh * 32 + (lane & 31)) * ldx;
-        float wb[kL1][NU], xa[NU];                               // the x operand is the same for every chunk
-        float bias[kL1];
-#pragma unroll
-        for (int i = 0; i < kL1; ++i) {
-            // no branch around these loads, not even the wave-uniform `chunk exists`: hipcc drains the loads of a
-            // conditional block at its join (s_waitcnt vmcnt(0) per chunk: four round trips in series, 10k cycles of a wave's
-            // 100k); a chunk that does not exist re-reads the last column and is never used
-            const int c0 = cw * 32 + 128 * i, cc = min(c0 + col, a.h1 - 1);
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int k = (lane >> 5) + 2 * u;
-                const float w = w1[(size_t)min(k, a.d_in - 1) * a.h1 + cc];            // clamped address, masked value
-                wb[i][u] = k < a.d_in ? w : 0.0f;
-            }
-            const float bv = b1[cc];
-            bias[i] = c0 + col < a.h1 ? bv : 0.0f;
-        }
+        float xa[NU];                                            // the x operand is the same for every chunk
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const int k = (lane >> 5) + 2 * u;
