@@ -1040,8 +1040,11 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float xv = xr[min(k0 + j, a.d_in - 1)];          // clamped address, masked value: no branches
-            v[j] = (e < a.E && k0 + j < a.d_in) ? xv : 0.0f;
+            // clamped address, value masked with an AND: written as `cond ? xv : 0` hipcc turns the select into a branch
+            // around the load and waits for each of the eight loads in turn (eight round trips in series at the head of
+            // every workgroup; found in the ISA in round 4)
+            const float xv = xr[min(k0 + j, a.d_in - 1)];
+            v[j] = __uint_as_float(__float_as_uint(xv) & ((e < a.E && k0 + j < a.d_in) ? 0xffffffffu : 0u));
         }
         Parts<P> xp;
 #pragma unroll
@@ -1065,12 +1068,22 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
             if (a.fin.episode_dev) epval[r] = (uint32_t)a.fin.episode_dev[e];
         }
     }
-    for (int idx = tid; idx < nb + 32; idx += 256) {               // biases -> LDS, zero padded
-        float v = 0.0f;
-        if (idx < a.nc1 * 32) { if (idx < a.h1) v = a.b1[(size_t)agent * a.h1 + idx]; }
-        else if (idx < nb) { if (idx - a.nc1 * 32 < a.h2) v = a.b2[(size_t)agent * a.h2 + idx - a.nc1 * 32]; }
-        else if (idx - nb < a.fin.nout) v = a.b3[(size_t)agent * a.fin.nout + idx - nb];
-        sbias[idx] = v;
+    {                                                              // biases -> LDS, zero padded: nb + 32 <= 1056 floats.  All
+        constexpr int kIt = 5;                                     // loads first, none behind a branch (same reason as above)
+        float bv[kIt];
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            const int idx = tid + 256 * it, j2 = idx - a.nc1 * 32, j3 = idx - nb;
+            const bool in1 = idx < a.nc1 * 32, in2 = idx < nb;
+            const float *p = in1 ? a.b1 + (size_t)agent * a.h1 + min(idx, a.h1 - 1)
+                           : in2 ? a.b2 + (size_t)agent * a.h2 + min(j2, a.h2 - 1)
+                                 : a.b3 + (size_t)agent * a.fin.nout + min(max(j3, 0), a.fin.nout - 1);
+            const bool ok = in1 ? idx < a.h1 : in2 ? j2 < a.h2 : j3 < a.fin.nout;
+            bv[it] = __uint_as_float(__float_as_uint(*p) & (ok ? 0xffffffffu : 0u));
+        }
+#pragma unroll
+        for (int it = 0; it < kIt; ++it)
+            if (tid + 256 * it < nb + 32) sbias[tid + 256 * it] = bv[it];
     }
     __syncthreads();
 
