@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(256) advantage_kernel(const float *__restrict_
         if (K1C > 0) {
             float v[kStageT], adv[kStageT];
             int j[kStageT][K1C > 0 ? K1C : 1];
+            float g[kStageT][K1C > 0 ? K1C : 1];
 #pragma unroll
             for (int u = 0; u < kStageT; ++u) {
                 const int t = min(t0 + u, T - 1);
@@ -278,12 +279,18 @@ __global__ void __launch_bounds__(256) advantage_kernel(const float *__restrict_
             for (int u = 0; u < kStageT; ++u) {
                 const int t = min(t0 + u, T - 1);
                 const float *Grow = G + (size_t)t * EN + e * N;
+#pragma unroll
+                for (int q = 0; q < K1C; ++q) g[u][q] = Grow[max(j[u][q], 0)];
+            }
+            // (all 8 K1 gathers are requested above before the first is used, and the "no neighbour" case is an AND mask:
+            // written as `j >= 0 ? gq - v : 0` hipcc puts a branch around every gather and waits for each in turn --
+            // 24 round trips in series per stage, found in the ISA in round 4)
+#pragma unroll
+            for (int u = 0; u < kStageT; ++u) {
                 float a = 0.0f;
 #pragma unroll
-                for (int q = 0; q < K1C; ++q) {
-                    const float gq = Grow[j[u][q] >= 0 ? j[u][q] : 0];
-                    a += j[u][q] >= 0 ? gq - v[u] : 0.0f;      // :345-346  (i itself is slot 0)
-                }
+                for (int q = 0; q < K1C; ++q)
+                    a += __uint_as_float(__float_as_uint(g[u][q] - v[u]) & (j[u][q] >= 0 ? 0xffffffffu : 0u));   // :345-346  (i itself is slot 0)
                 adv[u] = a;
             }
 #pragma unroll
