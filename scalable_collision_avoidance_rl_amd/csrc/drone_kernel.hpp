@@ -771,7 +771,14 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // for it sits at its first use INSIDE the loop -- a vmcnt(0) in front of the rewards and a vmcnt(1) at the loop top
     // that on every later step wait for the step's own output stores and the next action's prefetch instead (gfx950
     // counts loads and stores in one in-order counter)
-    if (MODE == kRollout && !rand_act)                        // (in-kernel actions: nothing is prefetched; measured +2 % with it)
+    // kSym64: NOT under the run-time `rand_act` of the episode-layer instances -- with the pin on one side of a branch
+    // only, the other side's pending loads reach the loop header and the in-loop waits are back for BOTH sides: the fused
+    // C3 rollout with pool actions and the episode layer ran 3.10-3.20 us per step against 2.89-2.95 with the pin on both
+    // (round 4).  The workgroup-per-env geometries keep the one-sided pin: pinned on both sides the C5 shard's rollout
+    // with pool actions and the episode layer goes from 2.46 to 2.72 us per step (same A/B, profiles/r4_abtest_rollout_pin.log)
+    // (a plain `s_waitcnt vmcnt(0)` builtin on the rand_act side instead of the operand pin does not clear the
+    // compiler's view of the pending loads: no gain)
+    if (MODE == kRollout && (SYM || !rand_act))
         asm volatile("" : : "v"(xi), "v"(yi), "v"(u0.x), "v"(u0.y), "v"(xFx), "v"(xFy), "v"(xLx), "v"(xLy), "v"(dhat), "v"(delta_i),
                      "v"(li), "v"(tcur), "v"(epi), "v"(accw.x), "v"(accw.y), "v"(accw.z), "v"(accw.w));
     float2 unext = make_float2(0.f, 0.f);                    // fused rollout: the next step's action, in flight

@@ -40,3 +40,16 @@ for spec in (sys.argv[1:] or ["c3"]):
             ts.append(a.elapsed_time(b) * 1e3 / T)
         us = min(ts)
         print(f"{spec} rollout T={T:4d}, {label}: {us:7.2f} us/step  {N*E/us*1e6:.3e} agent-steps/s  {44*N*E/us/1e3:7.1f} GB/s (44 B/agent-step)", flush=True)
+    # pool actions WITH the episode layer (dronesim_rollout_ex on an auto_reset env: what bench.py's fused_rollout times)
+    T = 200
+    env = drones(N, 0, [G, G], "O", deltas=np.ones(N) * delta, simplify_zstate=True, n_envs=E, batched=True, seed=1, auto_reset=True)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    act = torch.rand(T, E, N, 2, device="cuda", generator=g) * 2 - 1
+    out = env.rollout(act); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); out = env.rollout(act); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3 / T)
+    us = min(ts)
+    print(f"{spec} rollout T={T:4d}, pool actions + records + auto-reset: {us:7.2f} us/step  {N*E/us*1e6:.3e} agent-steps/s  {52*N*E/us/1e3:7.1f} GB/s (52 B/agent-step)", flush=True)
