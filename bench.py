@@ -216,7 +216,7 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
         if precision == "f32":
             out["policy_roofline"] = {"bound": "mfma", "achieved": flops / (pol_ms * 1e-3) / 1e12, "peak": 157.3,
                                       "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / 157.3,
-                                      "kernel": "mlp3_kernel (v_mfma_f32_32x32x2_f32, exact float32)"}
+                                      "kernel": "mlp3_kernel (v_mfma_f32_32x32x2_f32, layer 3 on v_mfma_f32_16x16x4_f32; exact float32)"}
         else:                                          # six bf16 products per float32-equivalent product on the 2.5 PFLOP/s pipe
             mf = 6.0 * flops
             out["policy_roofline"] = {"bound": "mfma", "achieved": mf / (pol_ms * 1e-3) / 1e12, "peak": 2500.0,
