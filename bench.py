@@ -208,9 +208,12 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
             for _ in range(20):
                 policy.sample_action(env.z, env=env)
         pg.replay(); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); pg.replay(); e1.record(); torch.cuda.synchronize()
-        pol_ms = e0.elapsed_time(e1) / 20
+        ts = []
+        for _ in range(5):                             # median of five replays (one alone still carries the clock ramp:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # it came out ABOVE the
+            e0.record(); pg.replay(); e1.record(); torch.cuda.synchronize()                       # in-the-loop step time)
+            ts.append(e0.elapsed_time(e1) / 20)
+        pol_ms = float(np.median(ts))
         flops = 2.0 * E * N * (policy.d_in * policy.h1 + policy.h1 * policy.h2 + policy.h2 * policy.nout)
         out["policy_kernel_ms"] = pol_ms
         if precision == "f32":
