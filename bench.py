@@ -195,7 +195,8 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
     steps = L * repeats
     kern_ms = step_kernel_ms(torch, env, pool, 5 * T_ep, reps=5)
     byt = algorithmic_bytes(N, E, True) + (36 * N * E if default_construction else 0)      # c = 5 rows: 60 B of z instead of 24
-    arith = {"f32": "exact float32 (v_mfma_f32_32x32x2_f32)", "bf16x3": "float32-accurate three-part bf16 split (6 x v_mfma_f32_32x32x16_bf16 per 16 k)"}.get(precision, precision)
+    arith = {"f32": "exact float32 (v_mfma_f32_32x32x2_f32)", "bf16x3": "float32-accurate three-part bf16 split (6 x v_mfma_f32_32x32x16_bf16 per 16 k)",
+             "f16x2": "float32-accurate two-part float16 split (3 x v_mfma_f32_32x32x16_f16 per 16 k; |activations| < 65504)"}.get(precision, precision)
     out = {"workload": label + (f" + {policy_kind} policy in the loop, {arith} (BASELINE configs[4], one shard)" if policy else ""),
            "value": N * E * steps / el, "unit": "agent-steps/s", "ms_per_step": el / steps * 1e3, "timed_steps": steps,
            "timed_seconds": el, "step_kernel_ms": kern_ms,
@@ -220,12 +221,14 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
             out["policy_roofline"] = {"bound": "mfma", "achieved": flops / (pol_ms * 1e-3) / 1e12, "peak": 157.3,
                                       "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / 157.3,
                                       "kernel": "mlp3_kernel (v_mfma_f32_32x32x2_f32, layer 3 on v_mfma_f32_16x16x4_f32; exact float32)"}
-        else:                                          # six bf16 products per float32-equivalent product on the 2.5 PFLOP/s pipe
-            mf = 6.0 * flops
+        else:                                          # six bf16 (three f16) products per float32-equivalent product on the 2.5 PFLOP/s pipe
+            nprod = 6.0 if precision == "bf16x3" else 3.0
+            mf = nprod * flops
             out["policy_roofline"] = {"bound": "mfma", "achieved": mf / (pol_ms * 1e-3) / 1e12, "peak": 2500.0,
                                       "unit": "TFLOP/s", "frac": mf / (pol_ms * 1e-3) / 1e12 / 2500.0,
                                       "float32_equivalent_tflops": flops / (pol_ms * 1e-3) / 1e12,
-                                      "kernel": "mlp3_split_kernel<SchemeBf16x3> (bf16 matrix flops actually issued: 6 per float32 product)"}
+                                      "kernel": "mlp3_split_kernel<%s> (16-bit matrix flops actually issued: %d per float32 product)"
+                                                % ("SchemeBf16x3" if precision == "bf16x3" else "SchemeF16x2", int(nprod))}
     del graph, env, pool
     torch.cuda.empty_cache()
     return out
@@ -681,7 +684,8 @@ def main():
             other = {}
             for key, wl, pk, pr in (("c2", "c2", None, "f32"), ("c5_env", "c5", None, "f32"),
                                     ("default_construction", "c3", None, "f32"),
-                                    ("c5_gaussian_f32", "c5", "gaussian", "f32"), ("c5_gaussian_bf16x3", "c5", "gaussian", "bf16x3")):
+                                    ("c5_gaussian_f32", "c5", "gaussian", "f32"), ("c5_gaussian_bf16x3", "c5", "gaussian", "bf16x3"),
+                                    ("c5_gaussian_f16x2", "c5", "gaussian", "f16x2")):
                 try:
                     other[key] = side_workload(torch, dev, wl, pk, precision=pr, default_construction=(key == "default_construction"))
                 except Exception as ex:                 # a side measurement must never cost the headline line
