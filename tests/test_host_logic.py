@@ -266,6 +266,30 @@ def test_no_step_kernel_spills():
     assert by[(2, 0, 0, 2, 0)][2] <= 64 and by[(2, 0, 0, 2, 1)][2] <= 80
 
 
+def test_policy_kernels_keep_their_occupancy():
+    """The batched policy kernels of the BUILT library: no scratch, and the register budgets their launch geometry
+    assumes -- the exact-f32 and split kernels run two workgroups of four waves per CU (<= 256 registers per wave, which
+    is also what makes hipcc pick the VGPR form of the matrix instructions: `__launch_bounds__(256, 2)`), the exact-f32
+    instance of the reference's observation width (d_in <= 6) leaves room for a third workgroup (<= 168) where LDS
+    allows it (h <= 200), the plain-bf16 kernels three to four (<= 168 / <= 128)."""
+    import shutil
+    from tools import kernel_resources as KR
+    if not os.path.exists(KR.READELF) and not shutil.which(KR.READELF):
+        pytest.skip("llvm-readelf not available")
+    lib = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "libdronesim.so")
+    rows = [r for r in KR.resources(lib) if "mlp3" in r[0]]
+    f32 = [r for r in rows if "mlp3_kernel" in r[0]]
+    split = [r for r in rows if "mlp3_split_kernel" in r[0]]
+    bf16 = [r for r in rows if "mlp3_bf16_kernel" in r[0]]
+    assert len(f32) == 5 and len(split) == 2 and len(bf16) == 16, [r[0] for r in rows]
+    assert all(r[4] == 0 for r in rows), [(r[0], r[4]) for r in rows if r[4]]
+    assert all(r[2] <= 256 for r in f32 + split), [(r[0], r[2]) for r in f32 + split]
+    assert all(r[2] <= 168 for r in f32 if "ILb1ELb1ELi3E" in r[0]), [(r[0], r[2]) for r in f32]
+    for r in bf16:
+        nc1 = int(r[0].split("mlp3_bf16_kernelILi")[1].split("E")[0])
+        assert r[2] <= (128 if nc1 <= 8 else 168), (r[0], r[2])
+
+
 def test_bench_refuses_a_multi_gpu_run_it_cannot_start():
     """`python bench.py --gpus N` with fewer than N visible GPUs (none in the build container) exits non-zero with a
     message instead of printing a one-rank line."""
