@@ -523,6 +523,55 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
         const bool ok = c0 + col < a.h2;
         const float bias = ok ? b2[c0 + col] : 0.0f;             // issued before the k-loop, needed after it
         f32x16 acc = {0};
+        // A single leftover chunk with at most 16 features (h2 = 400: the 13th chunk holds 16) is computed on the 16-column
+        // instruction: D[16 features][16 rows] x two row tiles x 4 k per step = 8 instructions of 32 cycles per 16 k
+        // instead of 8 of 64 on a tile whose other 16 feature rows are padding.  Lane (i = lane & 15, g = lane >> 4) takes
+        // k = 16 s + 4 g + t at step t of stage s: its four weights are ONE 16-byte piece of the chunk's ordinary packed
+        // stage ([q = g & 1][lane i + 32 (g >> 1)]: no other layout needed), its four h1 values one ds_read_b128 per row tile.
+        const bool half16 = TR && left && split == 4 && a.h2 - c0 <= 16;     // wave-uniform
+        if (half16) {
+            const int i16 = lane & 15, g4 = lane >> 4;
+            const f32x4 *Wp = reinterpret_cast<const f32x4 *>(w2 + (size_t)(c0 >> 5) * nst * 512) + (g4 & 1) * 64 + i16 + 32 * (g4 >> 1);
+            const float *hr0 = sh1 + i16 * ld1 + 4 * g4, *hr1 = hr0 + 16 * ld1;
+            const float bh = (part == 0 && c0 + i16 < a.h2) ? b2[c0 + i16] : 0.0f;
+            f32x4 ha[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
+            const int s0 = kb >> 4, sn = kn >> 4;
+            if (sn > 0) {
+                f32x4 wv = Wp[(size_t)s0 * 128];
+                f32x4 x0 = *reinterpret_cast<const f32x4 *>(hr0 + 16 * s0), x1 = *reinterpret_cast<const f32x4 *>(hr1 + 16 * s0);
+                for (int s1 = 0; s1 < sn; ++s1) {
+                    const int sx2 = s0 + min(s1 + 1, sn - 1);                     // next stage (the last one re-reads itself: no branch)
+                    const f32x4 wn = Wp[(size_t)sx2 * 128];
+                    const f32x4 y0 = *reinterpret_cast<const f32x4 *>(hr0 + 16 * sx2), y1 = *reinterpret_cast<const f32x4 *>(hr1 + 16 * sx2);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        ha[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], x0[t], ha[0], 0, 0, 0);
+                        ha[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], x1[t], ha[1], 0, 0, 0);
+                    }
+                    wv = wn; x0 = y0; x1 = y1;
+                }
+            }
+            if (part == 0) {                                     // bias on the matrix pipe (k slot of lanes 0..15), as in bias_mfma
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+                    ha[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g4 == 0 ? bh : 0.0f, g4 == 0 ? 1.0f : 0.0f, ha[rt], 0, 0, 0);
+            }
+            // D: register r of lane (i, g) = (feature 4 g + r, row 16 rt + i) -> this wave's partial tile [row][feature]
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) *reinterpret_cast<f32x4 *>(st + (rt * 16 + i16) * kSt + 4 * g4) = ha[rt];
+            __syncthreads();
+            if (part == 0) {
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    f32x4 *p = reinterpret_cast<f32x4 *>(st + (rt * 16 + i16) * kSt + 4 * g4);
+                    f32x4 v = ((p[0] + p[32 * kSt / 4]) + p[2 * 32 * kSt / 4]) + p[3 * 32 * kSt / 4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
+                    p[0] = v;
+                    p[4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};      // features 16 .. 31 of the staged chunk read as zero in layer 3
+                }
+            }
+        } else
         if (PACKED) {
             if (kn > 0)
                 tile_gemm_packed<POLICY_SETS, TR>(acc, sh1 + (rh * 32 + col) * ld1 + 8 * (lane >> 5),
@@ -530,7 +579,8 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
         } else if (kn > 0)
             tile_gemm(acc, sh1 + rh * 32 * ld1 + kb, ld1, w2 + c0 + (size_t)kb * a.h2, a.h2, kn, a.h2 - c0, lane);
         bool l3 = true;                                          // this wave feeds the chunk to layer 3
-        if (TR) {                                                // (packed W2 and the masked bias are zero beyond h2)
+        if (half16) l3 = part == 0;
+        else if (TR) {                                           // (packed W2 and the masked bias are zero beyond h2)
             if (!left || part == 0) acc = bias_mfma(acc, bias, lane);
             if (!left) store_tile_tr<true>(st + col * kSt, acc, lane);
             else {
