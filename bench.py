@@ -57,6 +57,12 @@ WORKLOADS = {
     "c3": (64, 4096, 28.0, 1.0, "C3: n=64 x 4096 envs/GPU, Delta=1.0, G=28, random actions"),
     "c5": (256, 512, 256.0, 2.5, "C5-shard: n=256 x 512 envs/GPU, Delta=2.5, G=256, random actions"),
 }
+# side lines only (`other_workloads`): the shapes that carry the "boundary amortised" part of the roofline argument
+SIDE_WORKLOADS = {
+    "c3_8192": (64, 8192, 28.0, 1.0, "n=64 x 8192 envs on one GPU (2 x C3), Delta=1.0, G=28, random actions"),
+    "c4_one_gpu": (64, 32768, 28.0, 1.0, "C4 as ONE job on one GPU: n=64 x 32768 envs (BASELINE configs[3] on one rank), Delta=1.0, G=28, random actions"),
+    "c5_full": (256, 4096, 256.0, 2.5, "C5 as ONE job on one GPU: n=256 x 4096 envs (BASELINE configs[4]'s env axis on one rank), Delta=2.5, G=256, random actions"),
+}
 
 
 def pmc_traffic(workload):
@@ -155,7 +161,7 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
     ``default_construction``: the reference's own defaults `drones(n, 0, grid, "O")` -- deltas=None (Delta = d_hat),
     simplify_zstate=False (15-column observation: 112 B per agent-step) -- drone_env.py:55, 85-87, 184."""
     from scalable_collision_avoidance_rl_amd import drones, max_time_steps
-    N, E, G, delta, label = WORKLOADS[name]
+    N, E, G, delta, label = WORKLOADS[name] if name in WORKLOADS else SIDE_WORKLOADS[name]
     if default_construction:
         env = drones(N, 0, [G, G], "O", n_envs=E, device=dev, seed=1234, batched=True, auto_reset=True, track_episodes=True)
         label = (f"reference defaults drones({N}, 0, [{G:g}, {G:g}], 'O'): deltas=None, simplify_zstate=False, k_closest=2; "
@@ -195,9 +201,10 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
     steps = L * repeats
     kern_ms = step_kernel_ms(torch, env, pool, 5 * T_ep, reps=5)
     byt = algorithmic_bytes(N, E, True) + (36 * N * E if default_construction else 0)      # c = 5 rows: 60 B of z instead of 24
+    cfg_note = "BASELINE configs[4], one shard" if (name == "c5" and policy_kind == "gaussian") else f"the reference's {policy_kind} networks (utils.py:255-309 / 55-117) at this shape"
     arith = {"f32": "exact float32 (v_mfma_f32_32x32x2_f32)", "bf16x3": "float32-accurate three-part bf16 split (6 x v_mfma_f32_32x32x16_bf16 per 16 k)",
              "f16x2": "float32-accurate two-part float16 split (3 x v_mfma_f32_32x32x16_f16 per 16 k; |activations| < 65504)"}.get(precision, precision)
-    out = {"workload": label + (f" + {policy_kind} policy in the loop, {arith} (BASELINE configs[4], one shard)" if policy else ""),
+    out = {"workload": label + (f" + {policy_kind} policy in the loop, {arith} ({cfg_note})" if policy else ""),
            "value": N * E * steps / el, "unit": "agent-steps/s", "ms_per_step": el / steps * 1e3, "timed_steps": steps,
            "timed_seconds": el, "step_kernel_ms": kern_ms,
            "roofline": {"bound": "hbm", "achieved": byt / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -230,6 +237,72 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
                                       "kernel": "mlp3_split_kernel<%s> (16-bit matrix flops actually issued: %d per float32 product)"
                                                 % ("SchemeBf16x3" if precision == "bf16x3" else "SchemeF16x2", int(nprod))}
     del graph, env, pool
+    torch.cuda.empty_cache()
+    return out
+
+
+def graph_time_us(torch, fn, calls, reps=5):
+    """Median duration of one `fn()` call in microseconds: HIP events (on torch's current stream = the stream the library
+    launches on) around a hipGraph that holds `calls` back-to-back calls."""
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(calls):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3 / calls)
+    del g
+    return float(np.median(ts))
+
+
+def aux_kernels(torch, dev):
+    """The kernels around the step launch, at the C3 rollout shape (T = 200 steps x 4096 envs x 64 agents), each with its
+    own HBM roofline on ALGORITHMIC bytes: the learner-side scans over a stored rollout (SAC_agents.py:304-307, 333-351),
+    env.reset() = reset kernel + first observation (drone_env.py:98-102, 171-212) and the classical controllers
+    (drone_env.py:609-679)."""
+    from scalable_collision_avoidance_rl_amd import drones
+    from scalable_collision_avoidance_rl_amd.rollout_buffer import mc_returns, neighbour_advantage
+    T, E, N = 200, 4096, 64
+    out = {}
+
+    def line(what, us, byt, kernel, note):
+        gbs = byt / (us * 1e-6) / 1e9
+        return {"workload": what, "us_per_call": us, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                 "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byt,
+                                                                 "kernel": kernel}, "note": note}
+    g = torch.Generator(device=dev).manual_seed(5)
+    r = torch.randn(T, E, N, device=dev, generator=g)
+    done = torch.zeros(T, E, dtype=torch.uint8, device=dev); done[-1] = 1
+    done[torch.randint(0, T, (E,), device=dev, generator=g), torch.arange(E, device=dev)] = 1   # one episode end per env somewhere
+    V = torch.randn(T, E, N, device=dev, generator=g)
+    nbr = torch.randint(-1, N, (T, E, N, 3), device=dev, dtype=torch.int32, generator=g)
+    nbr[..., 0] = torch.arange(N, device=dev, dtype=torch.int32)
+    us = graph_time_us(torch, lambda: mc_returns(r, 0.97, done), 8)
+    out["returns"] = line(f"Monte-Carlo returns over a stored rollout [T={T}, E={E}, N={N}] with episode ends (SAC_agents.py:304-307)",
+                          us, T * E * N * 8 + T * E, "returns_kernel", "reads reward 4 B + writes G 4 B per (step, agent), done 1 B per (step, env)")
+    G = mc_returns(r, 0.97, done)
+    us = graph_time_us(torch, lambda: neighbour_advantage(G, V, nbr, 0.97, done), 8)
+    out["advantage"] = line(f"neighbour-summed advantage weights [T={T}, E={E}, N={N}, k+1=3] (SAC_agents.py:333-351)",
+                            us, T * E * N * 24 + T * E, "advantage_kernel<3>",
+                            "reads G 4 + V 4 + nbr_idx 12 B, writes w 4 B per (step, agent); the neighbour gathers of G fall into the row just read (cache)")
+    del r, V, nbr, G, done
+    torch.cuda.empty_cache()
+    env = drones(N, 0, [28.0, 28.0], "O", k_closest=2, deltas=np.ones(N), simplify_zstate=True, n_envs=E, device=dev, seed=1234,
+                 batched=True)
+    us = graph_time_us(torch, lambda: env.reset(renew_obstacles=False), 20)
+    out["reset"] = line(f"env.reset() of all {E} envs of C3: lattice draw without replacement (reset_kernel) + first observation "
+                        "(drone_kernel<observe>) (drone_env.py:98-102, 171-212)", us, E * N * (16 + 16 + 36) + E * 12,
+                        "reset_kernel + drone_kernel<K=2,FAR=0,observe,plain>",
+                        "two launches: writes pos 8 + vel 8; reads them back 16, writes z 24 + nbr_idx 12 per agent; t / episode per env")
+    for kind, lines in (("proportional", "drone_env.py:652-679"), ("gradient", "drone_env.py:609-650")):
+        us = graph_time_us(torch, lambda: env.control(kind), 40)
+        out[f"control_{kind}"] = line(f"{kind}_control for all agents of C3 ({lines})", us, E * N * 16,
+                                      "control_kernel", "reads pos 8 B, writes act 8 B per agent: a 4 MB launch (launch-floor-bound)")
+    del env
     torch.cuda.empty_cache()
     return out
 
@@ -683,13 +756,20 @@ def main():
             torch.cuda.empty_cache()
             other = {}
             for key, wl, pk, pr in (("c2", "c2", None, "f32"), ("c5_env", "c5", None, "f32"),
+                                    ("c3_8192", "c3_8192", None, "f32"), ("c4_one_gpu", "c4_one_gpu", None, "f32"),
+                                    ("c5_full", "c5_full", None, "f32"),
                                     ("default_construction", "c3", None, "f32"),
                                     ("c5_gaussian_f32", "c5", "gaussian", "f32"), ("c5_gaussian_bf16x3", "c5", "gaussian", "bf16x3"),
-                                    ("c5_gaussian_f16x2", "c5", "gaussian", "f16x2")):
+                                    ("c5_gaussian_f16x2", "c5", "gaussian", "f16x2"),
+                                    ("c3_softmax16_f32", "c3", "softmax16", "f32")):
                 try:
                     other[key] = side_workload(torch, dev, wl, pk, precision=pr, default_construction=(key == "default_construction"))
                 except Exception as ex:                 # a side measurement must never cost the headline line
                     other[key] = {"error": f"{type(ex).__name__}: {ex}"}
+            try:                                        # learner-side scans, reset, controllers
+                other["aux_kernels"] = aux_kernels(torch, dev)
+            except Exception as ex:
+                other["aux_kernels"] = {"error": f"{type(ex).__name__}: {ex}"}
             out["other_workloads"] = other
         if world == 1 and not args.no_other_workloads and args.workload in ("c2", "c3", "c5") and policy is None and layer and not args.envs_per_gpu:
             torch.cuda.empty_cache()

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define DRONESIM_VERSION 400           /* 0.4.0: dronesim_step_call (pre-marshalled step arguments) */
+#define DRONESIM_VERSION 500           /* 0.5.0: the float64 verification entry points moved to libdronesim_verify.so (dronesim_verify.h) */
 #define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
 #define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
 
@@ -318,35 +318,6 @@ typedef struct DroneMlpBf16 {
 int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                               uint64_t seed, uint64_t counter, int64_t env_base,
                               const int32_t *t, const int32_t *episode, int E, void *stream);
-
-/* ---- float64 VERIFICATION variant (test infrastructure of the float32 product kernels; csrc/verify_f64.hip) -------
- * The reference computes in float64 (drone_env.py:189).  dronesim_step_f64 / dronesim_observe_f64 run the same
- * per-pair arithmetic (one scalar-type template, instantiated for double) and epilogue semantics as dronesim_step /
- * dronesim_observe on float64 buffers -- one workgroup per env, every ordered pair visited, no far filter: slow and
- * simple.  They exist so that the parity tests can (1) meet the reference's golden vectors with no float32-state
- * allowance, (2) follow a free-running 200-step episode of the float64 oracle, (3) judge the float32 kernels against
- * a float64 evaluation of the same state on the device.  Layouts as in dronesim_step with double instead of float.  */
-typedef struct DroneParamsF64 {
-    int32_t N;
-    int32_t k;
-    int32_t c;
-    int32_t max_steps;
-    double dt;
-    double q;
-    double b;
-    double done_radius;
-    double ghost_factor;
-    const double *xF;       /* [N][2] */
-    const double *d_hat;    /* [N]    */
-    const double *delta;    /* [N]    */
-    const double *radius;   /* [N]    */
-} DroneParamsF64;
-int dronesim_step_f64(const DroneParamsF64 *p, double *pos, double *vel, int32_t *t, const double *act,
-                      double *reward, double *true_reward, double *z, int32_t *nbr_idx,
-                      int32_t *n_coll, uint8_t *done, int E, void *stream);
-int dronesim_observe_f64(const DroneParamsF64 *p, const double *pos, const double *vel,
-                         double *reward, double *true_reward, double *z, int32_t *nbr_idx,
-                         int32_t *n_coll, int E, void *stream);
 
 /* float32-ACCURATE variant on the bf16 matrix instructions ("bf16x3"): every weight and activation is split by
  * truncation into three bf16 parts, v = hi + mid + lo exactly, and a product is the float32 sum of its six largest

@@ -14,6 +14,10 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # DRONESIM_LIB lets a developer A/B an alternative build of the SAME HIP library (no other backend exists)
 LIB_PATH = os.environ.get("DRONESIM_LIB") or os.path.join(_PKG, "libdronesim.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dronesim.h")
+# the float64 verification variant (test infrastructure) is a library of its own: the product library exports the product only
+VERIFY_LIB_PATH = os.environ.get("DRONESIM_VERIFY_LIB") or os.path.join(_PKG, "libdronesim_verify.so")
+VERIFY_HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "dronesim_verify.h")
+VERIFY_SYMBOLS = ("dronesim_step_f64", "dronesim_observe_f64", "dronesim_verify_last_error")
 
 OK, EINVAL, EUNSUPPORTED, ELAUNCH = 0, -1, -2, -3
 CONTROL_PROPORTIONAL, CONTROL_GRADIENT = 0, 1
@@ -25,7 +29,7 @@ STATS_SCRATCH_DOUBLES = 769          # DRONESIM_STATS_SCRATCH_DOUBLES (include/d
 EPISODE_REDUCE_DOUBLES = 8           # DRONESIM_EPISODE_REDUCE_DOUBLES
 SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_episode_stats", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
            "dronesim_step_ex", "dronesim_step_call", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
-           "dronesim_step_f64", "dronesim_observe_f64", "dronesim_mlp_forward_bf16x3", "dronesim_mlp_forward_f16x2", "dronesim_mlp_bf16x3_stages",
+           "dronesim_mlp_forward_bf16x3", "dronesim_mlp_forward_f16x2", "dronesim_mlp_bf16x3_stages",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -63,7 +67,7 @@ class DroneStepCall(C.Structure):
 
 
 class DroneParamsF64(C.Structure):
-    """Mirror of `struct DroneParamsF64` (include/dronesim.h): the float64 verification variant."""
+    """Mirror of `struct DroneParamsF64` (include/dronesim_verify.h): the float64 verification variant."""
     _fields_ = [("N", C.c_int32), ("k", C.c_int32), ("c", C.c_int32), ("max_steps", C.c_int32),
                 ("dt", C.c_double), ("q", C.c_double), ("b", C.c_double), ("done_radius", C.c_double),
                 ("ghost_factor", C.c_double),
@@ -141,10 +145,6 @@ def lib():
     L.dronesim_rollout_random.argtypes = [P, PC] + [vp] * 10 + [i32, i32, vp]
     L.dronesim_reset_ex.argtypes = [P, PC] + [vp] * 5 + [i32, vp]
     L.dronesim_episode_reduce.argtypes = [vp, i32, vp, vp]
-    P64 = C.POINTER(DroneParamsF64)
-    L.dronesim_step_f64.argtypes = [P64] + [vp] * 10 + [i32, vp]
-    L.dronesim_observe_f64.argtypes = [P64] + [vp] * 7 + [i32, vp]
-    L.dronesim_step_f64.restype = L.dronesim_observe_f64.restype = C.c_int
     for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset", "dronesim_step_ex",
                  "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
                  "dronesim_episode_stats", "dronesim_version"):
@@ -154,6 +154,35 @@ def lib():
     L.dronesim_error_string.argtypes = [C.c_int]
     _lib = L
     return L
+
+
+_vlib = None
+
+
+def verify_lib():
+    """Load libdronesim_verify.so (include/dronesim_verify.h): the float64 verification variant, test infrastructure."""
+    global _vlib
+    if _vlib is not None:
+        return _vlib
+    if not os.path.exists(VERIFY_LIB_PATH):
+        raise ImportError(f"{VERIFY_LIB_PATH} not found: run `make -C scalable_collision_avoidance_rl_amd/csrc` "
+                          "(hipcc, gfx950).  There is no CPU fallback.")
+    import torch  # noqa: F401  (same HIP runtime as the product library, see lib())
+    L = C.CDLL(VERIFY_LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    P64 = C.POINTER(DroneParamsF64)
+    L.dronesim_step_f64.argtypes = [P64] + [vp] * 10 + [i32, vp]
+    L.dronesim_observe_f64.argtypes = [P64] + [vp] * 7 + [i32, vp]
+    L.dronesim_step_f64.restype = L.dronesim_observe_f64.restype = C.c_int
+    L.dronesim_verify_last_error.restype = C.c_char_p
+    _vlib = L
+    return L
+
+
+def check_verify(rc, where):
+    if rc != OK:
+        raise DroneSimError(rc, where, f"{lib().dronesim_error_string(rc).decode()} -- "
+                                       f"{verify_lib().dronesim_verify_last_error().decode()}")
 
 
 def check(rc, where):

@@ -379,6 +379,12 @@ constexpr int kBlockStepWavesEpi = 6;      // (8 makes the episode-layer kernels
 // after an in-kernel reset still walked one exec-masked loop per word -- see the cold path; tests/test_gpu_fuzz.py and
 // test_rollout_with_pool_actions_equals_steps_across_resets guard it.)
 constexpr int kBlockRolloutEpiWaves = 4;
+// Round 5: the packed and the general workgroup-per-env rollouts of the episode layer (run-time choice of pool / in-kernel
+// actions, records, in-kernel reset: all of it live across the per-step loop) spilled 18-21 registers INSIDE the loop at
+// the 128-register budget; at 3 waves per SIMD (168 registers) the loop is spill-free (tests/test_host_logic.py:
+// test_no_rollout_kernel_spills_on_its_hot_path).  kBlockU256 (N = 256, uniform constants: BASELINE configs[4]) keeps
+// 4: its loop holds no spill at 128 registers (only the out-of-line reset does).
+constexpr int kRolloutEpiWaves = 3;
 
 template <int GEO> struct GeoTraits {
     static constexpr int kMaxThreads = GEO == kBlock1024 ? 1024 : 256;
@@ -394,7 +400,8 @@ template <int GEO> struct GeoTraits {
     {
         const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves
                                                                           : ((GEO == kBlock256 || GEO == kBlockU256) && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
-                                     : ((GEO == kBlock256 || GEO == kBlockU256) && epi) ? kBlockRolloutEpiWaves : 4;   // (the block rollout with the episode layer spills at 128 registers)
+                                     : (GEO == kBlockU256 && epi) ? kBlockRolloutEpiWaves
+                                     : ((GEO == kBlock256 || GEO == kPacked) && epi && !far) ? kRolloutEpiWaves : 4;
         const int cap = k <= 2 ? 8 : k <= 4 ? (((far || epi) && GEO == kBlock256 && mode != kRollout) ? 5 : 6) : 4;   // (k = 3 / 4, FAR or episode layer: 8-12 B of spills at 80 registers)
         return want < cap ? want : cap;
     }
@@ -1563,7 +1570,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 // wave waits for its own read first: written right here, a wave that ran ahead could hand a slower wave of
                 // the same env the INCREMENTED counter, i.e. another Philox stream for its 64 agents.  Round 4: found by the
                 // rollout fuzz of tests/test_gpu_fuzz.py as a 1-in-5 flake of multi-wave envs, present since round 2.)
-                if (!WL && !rand_act) __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): epi has arrived
+                if (!WL && !rand_act) {
+                    __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0): epi has arrived
+                    asm volatile("" : "+v"(epi) :: "memory");                      // ... and is a register value HERE: the load cannot
+                }                                                                 // sink behind the barrier where agent 0 stores epi + 1
                 if (WL && rs && agent == 0) c_episode[env] = (int)(epi + 1u);      // (one wave per env: nobody else reads it)
                 // terminal state of the finished episode (drone_env.py:258 returns it; the reset below overwrites it)
                 float *const c_pos_final = ca.pos_final, *const c_z_final = ca.z_final;

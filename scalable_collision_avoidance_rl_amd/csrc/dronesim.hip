@@ -204,6 +204,54 @@ struct DoneStage {
     __device__ __forceinline__ bool get(int de, int u) const { return __shfl((int)v, 8 * de + u, 64) != 0; }
 };
 
+// The scan is software-pipelined: the rewards (and done flags) of stage s + 1 are requested BEFORE stage s is folded and
+// stored, so that a thread always has kStageT .. 2 kStageT loads in flight and the sequential recurrence runs in the shadow
+// of the next stage's HBM round trip.  (Round 4 requested a stage, waited for all of it, folded, stored, and only then
+// requested the next: 4 waves per SIMD x 8 loads did not cover the round trip -- 84 us = 0.62 of the roofline against
+// 74 us for a copy of the same bytes.)  The recurrence itself is unchanged: G[t] = fma(G[t+1], gamma, r[t]), in order.
+constexpr int kRetStageT = 8;      // (the done-flag fetch of DoneStage covers 8 steps: see returns_fetch)
+struct RetStage {
+    float r[kRetStageT];
+    DoneStage ds;
+    bool last[kRetStageT];
+};
+
+template <bool COOP>
+__device__ __forceinline__ void returns_fetch(RetStage &st, const float *__restrict__ reward, const uint8_t *__restrict__ done,
+                                              size_t EN, size_t col, size_t e, size_t e_first, int E, int T, int t0)
+{
+    if (COOP) st.ds.fetch(done, e_first, E, T, [&](int u) { return t0 - u; });
+#pragma unroll
+    for (int u = 0; u < kRetStageT; ++u) {
+        const int t = t0 - u;
+        st.r[u] = t >= 0 ? __builtin_nontemporal_load(reward + (size_t)t * EN + col) : 0.0f;
+        if (!COOP) st.last[u] = t == T - 1 || (done != nullptr && t >= 0 && done[(size_t)t * E + e] != 0);
+    }
+}
+
+template <bool COOP>
+__device__ __forceinline__ void returns_scan(const float *__restrict__ reward, const uint8_t *__restrict__ done, float gamma,
+                                             float *__restrict__ G, int T, int E, size_t EN, size_t col, size_t e,
+                                             size_t e_first, int de, bool act)
+{
+    float g = 0.0f;
+    RetStage cur, nxt;
+    returns_fetch<COOP>(cur, reward, done, EN, col, e, e_first, E, T, T - 1);
+    for (int t0 = T - 1; t0 >= 0; t0 -= kRetStageT) {
+        if (t0 - kRetStageT >= 0) returns_fetch<COOP>(nxt, reward, done, EN, col, e, e_first, E, T, t0 - kRetStageT);
+#pragma unroll
+        for (int u = 0; u < kRetStageT; ++u) {
+            const int t = t0 - u;
+            if (t >= 0) {
+                const bool last = COOP ? (t == T - 1 || cur.ds.get(de, u)) : cur.last[u];
+                g = last ? cur.r[u] : fmaf(g, gamma, cur.r[u]);     // :306  Gt[t] = Gt[t+1]*discount + r[t]
+                if (act) __builtin_nontemporal_store(g, G + (size_t)t * EN + col);
+            }
+        }
+        cur = nxt;
+    }
+}
+
 __global__ void __launch_bounds__(256) returns_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done,
                                                       float gamma, float *__restrict__ G, int T, int E, int N)
 {
@@ -215,31 +263,8 @@ __global__ void __launch_bounds__(256) returns_kernel(const float *__restrict__ 
     const size_t e_first = (size_t)__shfl((long long)e, 0, 64);
     const int de = (int)(e - e_first);
     const bool coop = done != nullptr && __builtin_amdgcn_ballot_w64(de >= 8) == 0ull;
-    float g = 0.0f;
-    for (int t0 = T - 1; t0 >= 0; t0 -= kStageT) {
-        float r[kStageT];
-        bool last[kStageT];
-        DoneStage ds;
-        if (coop) ds.fetch(done, e_first, E, T, [&](int u) { return t0 - u; });
-#pragma unroll
-        for (int u = 0; u < kStageT; ++u) {
-            const int t = t0 - u;
-            r[u] = t >= 0 ? __builtin_nontemporal_load(reward + (size_t)t * EN + col) : 0.0f;
-            if (!coop) last[u] = t == T - 1 || (done != nullptr && t >= 0 && done[(size_t)t * E + e] != 0);
-        }
-        if (coop) {
-#pragma unroll
-            for (int u = 0; u < kStageT; ++u) last[u] = t0 - u == T - 1 || ds.get(de, u);
-        }
-#pragma unroll
-        for (int u = 0; u < kStageT; ++u) {
-            const int t = t0 - u;
-            if (t >= 0) {
-                g = last[u] ? r[u] : fmaf(g, gamma, r[u]);     // :306  Gt[t] = Gt[t+1]*discount + r[t]
-                if (act) __builtin_nontemporal_store(g, G + (size_t)t * EN + col);
-            }
-        }
-    }
+    if (coop) returns_scan<true>(reward, done, gamma, G, T, E, EN, col, e, e_first, de, act);
+    else returns_scan<false>(reward, done, gamma, G, T, E, EN, col, e, e_first, de, act);
 }
 
 // K1C = K + 1 at compile time (3 for the reference's k_closest = 2: the neighbour triple is one 12-byte load), 0 = any
@@ -572,10 +597,14 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
         // nearest, when the env's tile still fits (it does up to N = 1024 at k <= 5; the rows leave as 4-byte stores at a
         // 60-byte stride otherwise, as they all did through round 2)
         const size_t lds5 = drone_lds_bytes(g, p->N, p->k, 5), vel = sizeof(float2) * (size_t)g.epb * (size_t)p->N;
-        if (lds5 + vel + tail <= 160 * 1024) {
-            a.stage5 = 1; a.lds_vel = (int)lds5; g.lds = lds5 + vel;
+        // (the velocity region is rounded up to 16 bytes: the episode layer reads its per-wave partial sums behind it as
+        // ds_read_b128 -- 8 N bytes with odd N left `lds_tail` 8-byte aligned)
+        const size_t vel16 = (vel + 15) & ~(size_t)15;
+        if (lds5 + vel16 + tail <= 160 * 1024) {
+            a.stage5 = 1; a.lds_vel = (int)lds5; g.lds = lds5 + vel16;
         }
     }
+    g.lds = (g.lds + 15) & ~(size_t)15;                 // the tail's float4 reads (per-wave partial sums) need 16 bytes
     a.lds_tail = (int)g.lds;
     if (epi_regions) {
         g.lds += tail;

@@ -1,5 +1,5 @@
-// verify_f64.hip -- float64 VERIFICATION variant of the env step (test-only; include/dronesim.h: dronesim_step_f64 /
-// dronesim_observe_f64).  The reference is float64 throughout (drone_env.py:189); the product kernels of dronesim.hip
+// verify_f64.hip -- float64 VERIFICATION variant of the env step (test-only; include/dronesim_verify.h:
+// dronesim_step_f64 / dronesim_observe_f64; built as libdronesim_verify.so, NOT linked into the product library).  The reference is float64 throughout (drone_env.py:189); the product kernels of dronesim.hip
 // compute in float32, which forces two allowances in their parity tests (coordinate differences carry ulp32(G), and
 // free-running trajectories drift).  This kernel runs the SAME per-pair arithmetic (`pair_terms<Real>` of common.hpp,
 // instantiated for double) and the same epilogue semantics in float64 on the GPU, so that
@@ -14,8 +14,18 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "dronesim.h"
+#include <stdio.h>
+
+#include "dronesim_verify.h"
 #include "common.hpp"
+
+// this library's own error string (common.hpp declares the helper; the product library has its own definition)
+namespace { thread_local char g_verify_err[256] = ""; }
+__attribute__((visibility("hidden"))) int dronesim_fail(int code, const char *msg)
+{
+    snprintf(g_verify_err, sizeof(g_verify_err), "%s", msg);
+    return code;
+}
 
 namespace {
 
@@ -221,5 +231,7 @@ int dronesim_observe_f64(const DroneParamsF64 *p, const double *pos, const doubl
     a.reward = reward; a.true_reward = true_reward; a.z = z; a.nbr_idx = nbr_idx; a.n_coll = n_coll;
     return run(p, a, E, stream);
 }
+
+const char *dronesim_verify_last_error(void) { return g_verify_err; }
 
 }   // extern "C"

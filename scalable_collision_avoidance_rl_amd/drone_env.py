@@ -260,6 +260,7 @@ class drones:
                           n_coll=self.n_coll, done=self.done, z_final=self.z_final, nbr_final=self.nbr_final,
                           pos_final=self.pos_final)
         self._bound_home = True
+        self._z_ptr = self._home["_zptr"] = self.z.data_ptr()
         self._params_cache = None
         self._step_args = None
         # episode bookkeeping (include/dronesim.h: DroneEpisodeAcc, one 64-byte record per env) -- off unless asked for
@@ -341,11 +342,16 @@ class drones:
                                                           self.true_reward)
         views["_result"] = self._result
         self._bound_home = home
+        zp = views.get("_zptr")
+        if zp is None:
+            zp = views["_zptr"] = self.z.data_ptr()
+        self._z_ptr = zp                                  # where the current observation lives (see step(into=...))
 
     def _rebind_home(self):
         """After step(into=(storage, t)) the observation attributes are views of a storage slot.  Everything that
         writes through them outside step() (reset, set_state, load_state, rollout) first returns to the env's own
-        buffers, carrying the current observation over, so that stored experience is never clobbered."""
+        buffers, carrying the current observation over, so that stored experience is never clobbered.  The next
+        step(into=(storage, t + 1)) copies the (re-observed) observation into the ring slot it is the ``z_pre`` of."""
         if self._bound_home:
             return
         cur = dict(z=self.z, nbr_idx=self.nbr_idx, reward=self.reward, true_reward=self.true_reward, n_coll=self.n_coll,
@@ -453,6 +459,14 @@ class drones:
                 raise ValueError("step(into=...) needs the batched (tensor) API")
             storage, slot = into
             call, views = storage._slot(self, int(slot))
+            pre = views["_pre"]                              # ring slot that serves as `z_pre[slot]` / `nbr_pre[slot]`
+            if self._z_ptr != pre[2]:
+                # the current observation is not where this slot's pre-step observation is read from: a reset(mask) /
+                # set_state / load_state / rollout since the last step into the storage re-observed into the env's own
+                # buffers, or the storage was never begun -- carry it over, so that the stored (z_pre, action) pairs
+                # are the ones the policy acted on
+                pre[0].copy_(self.z)
+                pre[1].copy_(self.nbr_idx)
             av = views["actions"]
             if av is not None and act.data_ptr() != av.data_ptr():
                 av.copy_(act)                                # (a policy writing into storage.actions[t] avoids this)

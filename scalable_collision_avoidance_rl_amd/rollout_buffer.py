@@ -41,6 +41,9 @@ class RolloutStorage:
 
         storage = RolloutStorage(env, T)
         storage.begin()                                   # slot 0 of the ring <- the env's current observation
+        #                                                   (optional: a step into slot t carries the env's current
+        #                                                   observation into ring slot t itself when it lives elsewhere,
+        #                                                   e.g. after a manual `env.reset(mask=...)` between steps)
         for t in range(T):
             policy.sample_action(env.z, env=env, act_out=storage.actions[t])
             env.step(storage.actions[t], into=(storage, t))
@@ -103,7 +106,8 @@ class RolloutStorage:
             views = dict(reward=self.reward[t], true_reward=self.true_reward[t], z=self.zbuf[t + 1],
                          nbr_idx=self.nbrbuf[t + 1], n_coll=self.n_coll[t], done=self.done[t],
                          z_final=zf, nbr_final=nf, pos_final=env._home["pos_final"],
-                         actions=None if self.actions is None else self.actions[t])
+                         actions=None if self.actions is None else self.actions[t],
+                         _pre=(self.zbuf[t], self.nbrbuf[t], self.zbuf[t].data_ptr()))
             ctl = env._make_ctl(zf, nf, env._home["pos_final"]) if env._use_ctl else None
             env._params()
             self._slots[t] = (env._make_call(views, ctl), views)   # (the call keeps its ctl object alive)

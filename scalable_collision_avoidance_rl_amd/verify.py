@@ -1,4 +1,5 @@
-"""float64 verification variant of the env step on the GPU (include/dronesim.h: dronesim_step_f64 / dronesim_observe_f64).
+"""float64 verification variant of the env step on the GPU (include/dronesim_verify.h, libdronesim_verify.so:
+dronesim_step_f64 / dronesim_observe_f64).
 
 The reference is float64 throughout (drone_env.py:189) while the product kernels compute in float32.  `F64Env` runs
 the same per-pair arithmetic (one scalar-type template in csrc/common.hpp, instantiated for double) and the same
@@ -22,7 +23,7 @@ class F64Env:
                  collision_weight=0.2, drone_radius=None):
         import torch
         from . import _native
-        self._torch, self._native, self._lib = torch, _native, _native.lib()
+        self._torch, self._native, self._lib = torch, _native, _native.verify_lib()
         if not torch.cuda.is_available():
             raise RuntimeError("F64Env needs a ROCm GPU (there is no CPU path in this package)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -78,7 +79,7 @@ class F64Env:
             rc = self._lib.dronesim_observe_f64(C.byref(p), self.pos.data_ptr(), self.vel.data_ptr(), self.reward.data_ptr(),
                                                 self.true_reward.data_ptr(), self.z.data_ptr(), self.nbr_idx.data_ptr(),
                                                 self.n_coll.data_ptr(), self.n_envs, self._stream())
-        self._native.check(rc, "dronesim_observe_f64")
+        self._native.check_verify(rc, "dronesim_observe_f64")
 
     def step(self, actions):
         """drones.step() in float64 (drone_env.py:214-258): ``actions [E,N,2]`` float64 device tensor."""
@@ -92,5 +93,5 @@ class F64Env:
                                              act.data_ptr(), self.reward.data_ptr(), self.true_reward.data_ptr(),
                                              self.z.data_ptr(), self.nbr_idx.data_ptr(), self.n_coll.data_ptr(),
                                              self.done.data_ptr(), self.n_envs, self._stream())
-        self._native.check(rc, "dronesim_step_f64")
+        self._native.check_verify(rc, "dronesim_step_f64")
         return self

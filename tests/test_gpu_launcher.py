@@ -84,6 +84,49 @@ def test_bench_py_runs_with_two_ranks_on_one_device():
     assert [r["rank"] for r in out["per_rank"]] == [0, 1] and all(r["step_kernel_ms"] > 0 and r["envs"] == 512 for r in out["per_rank"])
 
 
+def test_bench_py_runs_with_eight_ranks_on_one_device():
+    """The shape of the driver's first SCALE run, on the one GPU a box has: `bench.py --gpus 8` as 8 ranks (gloo, all on
+    device 0, 100 envs each): one JSON line from rank 0 with whole-job figures, `per_rank` for all 8 ranks, the exchange
+    inside the timed region with its `rccl_ranks` / `backend` fields, every launch accounted for by the device records.
+    (Ragged shards over 8 ranks: the next test.)"""
+    r = _launch(8, "bench.py", ["--gpus", 8, "--steps", 20, "--warmup", 2, "--envs-per-gpu", 100, "--min-seconds", 0.03,
+                                "--no-cpu-baseline"], extra_env=dict(BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1"), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["config"]["n_envs_total"] == 800 and out["config"]["parallelism"] == "env-shard x8"
+    assert out["scaling"] == "weak" and out["value"] == pytest.approx(64 * 800 * out["timed_steps"] / out["timed_seconds"], rel=1e-9)
+    ex = out["exchange"]
+    assert ex["real_collective_ran"] is True and ex["backend"] == "gloo" and "rccl_ranks" in ex and ex["rccl_ranks"] == 0
+    assert ex["collectives_in_timed_region"] == out["repeats"] and ex["collective_latency_us"] > 0
+    assert [q["rank"] for q in out["per_rank"]] == list(range(8))
+    assert all(q["envs"] == 100 and q["step_kernel_ms"] > 0 and q["timed_seconds"] > 0 for q in out["per_rank"])
+    assert out["launch_check"]["ok"] is True and out["episode_end_stats"]["world_size"] == 8
+    assert out["launch_check"]["env_steps_recorded_all_ranks"] == out["launch_check"]["launches_issued_per_rank"] * 800
+
+
+def test_ragged_shards_over_eight_ranks_reproduce_one_rank(tmp_path):
+    """99 envs over 8 ranks (shards of 13 / 12 envs): the product path per rank, bit-identical to one rank."""
+    worker = os.path.join("tests", "launch_worker.py")
+    many, one = tmp_path / "many", tmp_path / "one"
+    many.mkdir(); one.mkdir()
+    N, G, E, T, W = 5, 5.0, 99, 60, 8
+    r = _launch(W, worker, [many, N, G, E, T], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, worker, str(one), str(N), str(G), str(E), str(T)], cwd=ROOT,
+                       env=dict(os.environ, RANK="0", WORLD_SIZE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    full = np.load(one / "rank0.npz")
+    parts = [np.load(many / f"rank{k}.npz") for k in range(W)]
+    sizes = [int(p["hi"]) - int(p["lo"]) for p in parts]
+    assert sum(sizes) == E and max(sizes) - min(sizes) == 1 and int(parts[0]["lo"]) == 0 and int(parts[-1]["hi"]) == E
+    for name in ("pos", "z", "nbr", "acc", "last_reward"):
+        assert np.array_equal(np.concatenate([p[name] for p in parts]), full[name]), name
+    for name in ("reward", "done"):
+        assert np.array_equal(np.concatenate([p[name] for p in parts], axis=1), full[name]), name
+
+
 def test_bench_py_starts_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` with NO launcher and NO WORLD_SIZE in the environment (how the driver's scaling run
     may call it): bench.py re-runs itself as 2 ranks, and the line is a 2-rank line -- never a silent one-rank run."""

@@ -64,9 +64,25 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == sorted(_native.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dronesim_version() == 400
+    assert lib.dronesim_version() == 500
     assert lib.dronesim_error_string(0) == b"ok"
     assert b"invalid" in lib.dronesim_error_string(_native.EINVAL)
+
+
+def test_product_library_exports_the_product_only():
+    """The float64 verification variant (test infrastructure) lives in libdronesim_verify.so / include/dronesim_verify.h:
+    the product library exports no *_f64 symbol, and the verification library exports what its header declares."""
+    import subprocess
+    vheader = open(_native.VERIFY_HEADER_PATH).read()
+    declared = sorted(set(re.findall(r"\b(dronesim_[a-z0-9_]+)\s*\(", vheader)))
+    assert declared == sorted(_native.VERIFY_SYMBOLS)
+    vlib = _native.verify_lib()
+    for name in declared:
+        assert getattr(vlib, name) is not None
+    out = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True).stdout
+    exported = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert exported and not [n for n in exported if "f64" in n.lower()], [n for n in exported if "f64" in n.lower()]
+    assert not hasattr(_native.lib(), "dronesim_step_f64")
 
 
 def test_params_struct_layout_matches_header():
@@ -80,11 +96,14 @@ def test_params_struct_layout_matches_header():
 def test_episode_structs_match_header():
     """ctypes mirrors of DroneEpisodeAcc / DroneEpisodeCtl (field order, sizes) against include/dronesim.h."""
     header = open(_native.HEADER_PATH).read()
+    vheader = open(_native.VERIFY_HEADER_PATH).read()
     for cls, name in ((_native.DroneEpisodeAcc, "DroneEpisodeAcc"), (_native.DroneEpisodeCtl, "DroneEpisodeCtl"),
                       (_native.DroneParamsF64, "DroneParamsF64")):
+        header = vheader if name == "DroneParamsF64" else open(_native.HEADER_PATH).read()
         body = header[header.index("typedef struct %s {" % name):header.index("} %s;" % name)]
         names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|int64_t|uint64_t|float|double|DroneEpisodeAcc)\s*\*?\s*(\w+);", body, re.M)
         assert names == [f[0] for f in cls._fields_], name
+    header = open(_native.HEADER_PATH).read()
     body = header[header.index("typedef struct DroneStepCall {"):header.index("} DroneStepCall;")]
     names = re.findall(r"^\s*(?:const\s+)?(?:int32_t|uint8_t|float|DroneParams|DroneEpisodeCtl)\s*\*?\s*(\w+);", body, re.M)
     assert names == [f[0] for f in _native.DroneStepCall._fields_] and C.sizeof(_native.DroneStepCall) == 11 * 8 + 8
@@ -264,6 +283,31 @@ def test_no_step_kernel_spills():
     assert by[(2, 0, 0, 1, 1)][2] <= 64 and by[(2, 0, 0, 1, 0)][2] <= 64
     # C5's kernels (workgroup-per-env, N <= 256): plain 8 waves per SIMD, episode layer 6 (<= 80 VGPRs)
     assert by[(2, 0, 0, 2, 0)][2] <= 64 and by[(2, 0, 0, 2, 1)][2] <= 80
+
+
+def test_no_rollout_kernel_spills_on_its_hot_path():
+    """Fused rollouts (MODE = 2) of the BUILT library at k = 2 without far agents -- every BASELINE shape: kPacked (C2),
+    kSym64 (C3 / C4), kBlockU256 (C5), and kBlock256 (65 ... 255 agents) -- with and without the episode layer: NO scratch
+    instruction inside the per-step loop (tools/spill_sites.py: the largest loop of the ISA by layout).  What scratch an
+    episode-layer kernel does use sits in the out-of-line in-kernel reset (once per episode and env), laid out behind
+    the loop; the plain kernels of the one-env-per-wave and N = 256 geometries use none at all."""
+    import shutil
+    from tools import kernel_resources as KR
+    from tools import spill_sites as SS
+    if not os.path.exists(KR.READELF) and not shutil.which(KR.READELF):
+        pytest.skip("llvm-readelf not available")
+    lib = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "libdronesim.so")
+    for geo in (0, 1, 2, 4):
+        for epi in (0, 1):
+            r = SS.hot_loop_scratch(lib, 2, 0, 2, geo, epi)
+            assert r is not None, (geo, epi)
+            n_ins, loop, hot, total = r
+            assert loop is not None and loop[1] - loop[0] > 500, (geo, epi, loop)      # the per-step loop was found
+            assert hot == 0, f"GEO={geo} EPI={epi}: {hot} scratch instructions inside the per-step loop {loop}"
+            if geo in (1, 4) and epi == 0:
+                assert total == 0, (geo, epi, total)
+    # kSym64 with the episode layer (bench.py's fused_rollout line): no scratch anywhere
+    assert SS.hot_loop_scratch(lib, 2, 0, 2, 1, 1)[3] == 0
 
 
 def test_policy_kernels_keep_their_occupancy():

@@ -4,7 +4,7 @@
 
     python tools/abtest.py <rounds> <cases> lib_a.so lib_b.so ...
     cases: comma list of  c3 (plain step) | c3e (step, episode layer + auto-reset: the graded kernel) | c3r (fused rollout)
-           | c3rr (fused rollout, actions drawn in the kernel, episode layer) | c5 | c5e | c5r | c2 | NxE:G:delta[e|r]
+           | c3rr (fused rollout, actions drawn in the kernel, episode layer) | c3re (fused rollout, pool actions, episode layer) | c5 | c5e | c5r | c2 | NxE:G:delta[e|r]
            | c3f / c5f / NxE:G:deltaf (the reference's DEFAULT construction: deltas=None, simplify_zstate=False -> FAR variant)
 
 Every (round, library) runs in its own process (the library is chosen at import time through DRONESIM_LIB)."""
@@ -27,7 +27,7 @@ def one(cases):
     for case in cases:
         mode = "plain"
         spec = case
-        for suffix, m in (("rr", "rollout_random"), ("r", "rollout"), ("e", "epi"), ("f", "far")):
+        for suffix, m in (("rr", "rollout_random"), ("re", "rollout_epi"), ("r", "rollout"), ("e", "epi"), ("f", "far")):
             if spec.endswith(suffix) and (spec[:-len(suffix)] in PRESETS or ":" in spec):
                 spec, mode = spec[:-len(suffix)], m
                 break
@@ -36,7 +36,7 @@ def one(cases):
         else:
             ne, G, delta = spec.split(":")
             N, E = (int(x) for x in ne.split("x")); G, delta = float(G), float(delta)
-        kw = dict(auto_reset=True) if mode in ("epi", "rollout_random") else {}
+        kw = dict(auto_reset=True) if mode in ("epi", "rollout_random", "rollout_epi") else {}
         if mode == "far":        # the reference's DEFAULT construction: deltas=None (Delta = d_hat), simplify_zstate=False (c = 5)
             env = drones(N, 0, [G, G], "O", n_envs=E, batched=True, seed=1)
         else:
