@@ -48,6 +48,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_AGENT_STEP = 76        # reads pos 8 + act 8; writes pos 8, vel 8, r 4, true_r 4, z 24, nbr 12
 BYTES_PER_ENV_STEP = 13          # n_coll 4 + done 1 + t read/write 8
 BYTES_PER_ENV_STEP_RECORD = 64   # episode layer: the hot 32 bytes of the env's DroneEpisodeAcc record, read + written
+# launcher tests with many ranks on ONE device shrink the secondary measurements (the graded region is untouched by these):
+EAGER_MIN_STEPS = int(os.environ.get("BENCH_EAGER_MIN_STEPS", "1000"))      # steps of the eager side figure
+KERNEL_SAMPLE_EPISODES = int(os.environ.get("BENCH_KERNEL_SAMPLE_EPISODES", "20"))   # episodes in the step-kernel timing graph
 GRAPH_LAUNCHES = int(os.environ.get("BENCH_GRAPH_LAUNCHES", "4000"))   # launches captured into the one replayed graph
 #                                  (profiles/r4_graph_size_probe.log: 2000 -> 5.20 us/step, 4000 -> 5.14, 16000 -> 5.31)
 
@@ -501,7 +504,7 @@ def main():
     torch.cuda.synchronize()
 
     # secondary figure: the same K steps launched eagerly from Python (host launch latency included)
-    eager_steps = max(args.steps, 1000) if policy is None else args.steps     # (a 20-step loop would mostly time its two syncs)
+    eager_steps = max(args.steps, EAGER_MIN_STEPS) if policy is None else args.steps     # (a 20-step loop would mostly time its two syncs)
     barrier()
     t0 = time.perf_counter()
     for s in range(eager_steps):
@@ -610,7 +613,7 @@ def main():
     # duration including the dependent-launch boundary and excluding host launch latency.  rocprofv3 --kernel-trace
     # --stats of this command reports the same kernel's average duration (profiles/).  With the episode layer the graph
     # holds twenty episodes (the in-kernel resets fire inside it, as in the timed region).
-    kern_ms = step_kernel_ms(torch, env, pool, 20 * T_ep if layer else T_ep)
+    kern_ms = step_kernel_ms(torch, env, pool, KERNEL_SAMPLE_EPISODES * T_ep if layer else T_ep)
 
     # secondary figure: the same workload through dronesim_rollout (200 steps fused in ONE launch, actions
     # known up front -- RandomAgent rollouts); every per-step output except the per-step state is written
@@ -727,7 +730,7 @@ def main():
             "episode_end_stats": summary,
             "eager": {"value": N * E_global * eager_steps / eager_elapsed, "ms_per_step": eager_elapsed / eager_steps * 1e3,
                       "steps": eager_steps,
-                      "note": "max(K, 1000) steps launched one by one from Python, no hipGraph (host launch latency included)"},
+                      "note": f"max(K, {EAGER_MIN_STEPS}) steps launched one by one from Python, no hipGraph (host launch latency included)"},
             "fused_rollout": None if ro_us is None else {
                 "us_per_step_per_gpu": ro_us, "agent_steps_per_s_per_gpu": N * E / ro_us * 1e6,
                 "roofline_frac_52B": 52.0 * N * E / (ro_us * 1e-6) / 1e9 / HBM_PEAK_GBS,

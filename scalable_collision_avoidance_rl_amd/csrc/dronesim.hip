@@ -210,61 +210,77 @@ struct DoneStage {
 // requested the next: 4 waves per SIMD x 8 loads did not cover the round trip -- 84 us = 0.62 of the roofline against
 // 74 us for a copy of the same bytes.)  The recurrence itself is unchanged: G[t] = fma(G[t+1], gamma, r[t]), in order.
 constexpr int kRetStageT = 8;      // (the done-flag fetch of DoneStage covers 8 steps: see returns_fetch)
-struct RetStage {
-    float r[kRetStageT];
+// V = 4: a thread owns FOUR adjacent columns (agents of one env: N % 4 == 0) and moves them as 16-byte loads / stores --
+// a quarter of the memory instructions for the same bytes in flight (round 5; the un-pipelined round-4 scan lost with
+// four columns per thread because a wave then had nothing to overlap its stage wait with).  V = 1: any shape.
+template <int V> struct RetVec;
+template <> struct RetVec<1> { typedef float type; };
+template <> struct RetVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <int V> struct RetStage {
+    typename RetVec<V>::type r[kRetStageT];
     DoneStage ds;
     bool last[kRetStageT];
 };
 
-template <bool COOP>
-__device__ __forceinline__ void returns_fetch(RetStage &st, const float *__restrict__ reward, const uint8_t *__restrict__ done,
+template <bool COOP, int V>
+__device__ __forceinline__ void returns_fetch(RetStage<V> &st, const float *__restrict__ reward, const uint8_t *__restrict__ done,
                                               size_t EN, size_t col, size_t e, size_t e_first, int E, int T, int t0)
 {
+    typedef typename RetVec<V>::type vec;
     if (COOP) st.ds.fetch(done, e_first, E, T, [&](int u) { return t0 - u; });
 #pragma unroll
     for (int u = 0; u < kRetStageT; ++u) {
         const int t = t0 - u;
-        st.r[u] = t >= 0 ? __builtin_nontemporal_load(reward + (size_t)t * EN + col) : 0.0f;
+        st.r[u] = t >= 0 ? __builtin_nontemporal_load(reinterpret_cast<const vec *>(reward + (size_t)t * EN + col)) : vec(0.0f);
         if (!COOP) st.last[u] = t == T - 1 || (done != nullptr && t >= 0 && done[(size_t)t * E + e] != 0);
     }
 }
 
-template <bool COOP>
+template <bool COOP, int V>
 __device__ __forceinline__ void returns_scan(const float *__restrict__ reward, const uint8_t *__restrict__ done, float gamma,
                                              float *__restrict__ G, int T, int E, size_t EN, size_t col, size_t e,
                                              size_t e_first, int de, bool act)
 {
-    float g = 0.0f;
-    RetStage cur, nxt;
-    returns_fetch<COOP>(cur, reward, done, EN, col, e, e_first, E, T, T - 1);
+    typedef typename RetVec<V>::type vec;
+    vec g = vec(0.0f);
+    RetStage<V> cur, nxt;
+    returns_fetch<COOP, V>(cur, reward, done, EN, col, e, e_first, E, T, T - 1);
     for (int t0 = T - 1; t0 >= 0; t0 -= kRetStageT) {
-        if (t0 - kRetStageT >= 0) returns_fetch<COOP>(nxt, reward, done, EN, col, e, e_first, E, T, t0 - kRetStageT);
+        if (t0 - kRetStageT >= 0) returns_fetch<COOP, V>(nxt, reward, done, EN, col, e, e_first, E, T, t0 - kRetStageT);
 #pragma unroll
         for (int u = 0; u < kRetStageT; ++u) {
             const int t = t0 - u;
             if (t >= 0) {
                 const bool last = COOP ? (t == T - 1 || cur.ds.get(de, u)) : cur.last[u];
-                g = last ? cur.r[u] : fmaf(g, gamma, cur.r[u]);     // :306  Gt[t] = Gt[t+1]*discount + r[t]
-                if (act) __builtin_nontemporal_store(g, G + (size_t)t * EN + col);
+                if (V == 1) {
+                    g = last ? cur.r[u] : vec(fmaf(*reinterpret_cast<float *>(&g), gamma, *reinterpret_cast<const float *>(&cur.r[u])));   // :306  Gt[t] = Gt[t+1]*discount + r[t]
+                } else {
+                    float *gp = reinterpret_cast<float *>(&g);
+                    const float *rp = reinterpret_cast<const float *>(&cur.r[u]);
+#pragma unroll
+                    for (int q = 0; q < V; ++q) gp[q] = last ? rp[q] : fmaf(gp[q], gamma, rp[q]);                                         // :306
+                }
+                if (act) __builtin_nontemporal_store(g, reinterpret_cast<vec *>(G + (size_t)t * EN + col));
             }
         }
         cur = nxt;
     }
 }
 
+template <int V>
 __global__ void __launch_bounds__(256) returns_kernel(const float *__restrict__ reward, const uint8_t *__restrict__ done,
                                                       float gamma, float *__restrict__ G, int T, int E, int N)
 {
     const size_t EN = (size_t)E * N;
-    const size_t col0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t col0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     const bool act = col0 < EN;                               // (no early exit: the flag fetch is a wave operation)
-    const size_t col = act ? col0 : EN - 1;
-    const size_t e = col / N;
+    const size_t col = act ? col0 : EN - V;
+    const size_t e = col / N;                                 // (V == 4: N % 4 == 0, the four columns belong to one env)
     const size_t e_first = (size_t)__shfl((long long)e, 0, 64);
     const int de = (int)(e - e_first);
     const bool coop = done != nullptr && __builtin_amdgcn_ballot_w64(de >= 8) == 0ull;
-    if (coop) returns_scan<true>(reward, done, gamma, G, T, E, EN, col, e, e_first, de, act);
-    else returns_scan<false>(reward, done, gamma, G, T, E, EN, col, e, e_first, de, act);
+    if (coop) returns_scan<true, V>(reward, done, gamma, G, T, E, EN, col, e, e_first, de, act);
+    else returns_scan<false, V>(reward, done, gamma, G, T, E, EN, col, e, e_first, de, act);
 }
 
 // K1C = K + 1 at compile time (3 for the reference's k_closest = 2: the neighbour triple is one 12-byte load), 0 = any
@@ -830,8 +846,14 @@ int dronesim_returns(const float *reward, const uint8_t *done, float gamma, floa
     if (!reward || !G || T < 0 || E < 0 || N < 1) return fail(DRONESIM_EINVAL, "dronesim_returns: bad argument");
     if (T == 0 || E == 0) return DRONESIM_OK;
     const size_t cols = (size_t)E * N;
-    hipLaunchKernelGGL(returns_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       reward, done, gamma, G, T, E, N);
+    // 16-byte columns quadruples when every row of the [T][E N] arrays starts 16-byte aligned and an env's agents come in fours
+    const bool v4 = (N % 4) == 0 && ((reinterpret_cast<uintptr_t>(reward) | reinterpret_cast<uintptr_t>(G)) & 15u) == 0;
+    if (v4)
+        hipLaunchKernelGGL(returns_kernel<4>, dim3((unsigned)((cols / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           reward, done, gamma, G, T, E, N);
+    else
+        hipLaunchKernelGGL(returns_kernel<1>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           reward, done, gamma, G, T, E, N);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

@@ -90,7 +90,10 @@ def test_bench_py_runs_with_eight_ranks_on_one_device():
     inside the timed region with its `rccl_ranks` / `backend` fields, every launch accounted for by the device records.
     (Ragged shards over 8 ranks: the next test.)"""
     r = _launch(8, "bench.py", ["--gpus", 8, "--steps", 20, "--warmup", 2, "--envs-per-gpu", 100, "--min-seconds", 0.03,
-                                "--no-cpu-baseline"], extra_env=dict(BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1"), timeout=900)
+                                "--no-cpu-baseline"],
+                # (eight processes time-slice one GPU: the secondary measurements are shrunk, the graded region is not)
+                extra_env=dict(BENCH_BACKEND="gloo", BENCH_ONE_DEVICE="1", BENCH_EAGER_MIN_STEPS="40", BENCH_KERNEL_SAMPLE_EPISODES="1",
+                               BENCH_GRAPH_LAUNCHES="400"), timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

@@ -814,7 +814,9 @@ def _modules(fx, prefix, names):
     return mods
 
 
-@pytest.mark.parametrize("T,E,N,K1", [(13, 37, 3, 3), (9, 11, 5, 3), (17, 70, 2, 2), (21, 9, 7, 4), (40, 3, 64, 3)])
+@pytest.mark.parametrize("T,E,N,K1", [(13, 37, 3, 3), (9, 11, 5, 3), (17, 70, 2, 2), (21, 9, 7, 4), (40, 3, 64, 3),
+                                      # N % 4 == 0: the returns scan moves four columns per thread as 16-byte accesses
+                                      (33, 70, 4, 3), (19, 5, 128, 3), (12, 301, 8, 3), (200, 6, 64, 3)])
 def test_learner_scans_done_flag_paths(torch, T, E, N, K1):
     """The scans fetch the done flags once per wave (up to 8 envs per wave) and fall back to per-thread reads when a
     wave's columns span more envs (N < 8 with many envs); both against the oracle, with a ragged last wave."""
