@@ -64,7 +64,12 @@ constexpr int kBucketMax = 10;      // candidates per agent beyond which the all
 constexpr int kFarAllMaxN = 8;      // FAR variant: envs this small send every pair through pass 2 (no filter, no far tail)
 constexpr float kLn2 = 0.693147180559945309f;
 
-enum Mode { kStep = 0, kObserve = 1, kRollout = 2 };
+// kRolloutPool / kRolloutRand: the fused rollout of the episode layer with its action source known at COMPILE time (pool
+// actions / actions drawn in the kernel) -- the one-env-per-wave and N = 256 geometries (every BASELINE shape's rollout):
+// no run-time `rand_act` branches in the per-step loop and none of the other source's registers live across it (round 5).
+// kRollout itself keeps the run-time flag (the other geometries, and every plain rollout).
+enum Mode { kStep = 0, kObserve = 1, kRollout = 2, kRolloutPool = 3, kRolloutRand = 4 };
+constexpr bool is_rollout(int mode) { return mode >= kRollout; }
 
 // Developer trace builds (-DDRONESIM_TRACE / -DDRONESIM_TRACE_FINE: kTrace / kTraceFine of common.hpp) stamp per-wave
 // phase times into KArgs.trace; in the product build the stamps are dead code.  TRACE_FINE moves stamps 1 and 2 into the
@@ -398,11 +403,11 @@ template <int GEO> struct GeoTraits {
     // (FAR: the c = 5 rows and the far tail want registers too -- at 64 the C5-sized default construction was 7.6 % slower)
     static constexpr int min_waves(int k, int mode, bool epi, bool far)
     {
-        const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && mode != kRollout) ? kSymStepWaves
-                                                                          : ((GEO == kBlock256 || GEO == kBlockU256) && mode != kRollout) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
+        const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && !is_rollout(mode)) ? kSymStepWaves
+                                                                          : ((GEO == kBlock256 || GEO == kBlockU256) && !is_rollout(mode)) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
                                      : (GEO == kBlockU256 && epi) ? kBlockRolloutEpiWaves
                                      : ((GEO == kBlock256 || GEO == kPacked) && epi && !far) ? kRolloutEpiWaves : 4;
-        const int cap = k <= 2 ? 8 : k <= 4 ? (((far || epi) && GEO == kBlock256 && mode != kRollout) ? 5 : 6) : 4;   // (k = 3 / 4, FAR or episode layer: 8-12 B of spills at 80 registers)
+        const int cap = k <= 2 ? 8 : k <= 4 ? (((far || epi) && GEO == kBlock256 && !is_rollout(mode)) ? 5 : 6) : 4;   // (k = 3 / 4, FAR or episode layer: 8-12 B of spills at 80 registers)
         return want < cap ? want : cap;
     }
     static constexpr bool kWaveLocal = GEO == kPacked || GEO == kSym64;
@@ -528,13 +533,14 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // episode bookkeeping (dronesim_*_ex): the running sums of an env's DroneEpisodeAcc record live in the registers
     // of its agent-0 lane for the whole launch; `epi` = resets the env has seen (stream id of reset and actions)
     static_assert(!(EPI && MODE == kObserve), "observe has no episode bookkeeping");
+    static_assert(!((MODE == kRolloutPool || MODE == kRolloutRand) && !EPI), "the compile-time action source belongs to the episode layer");
     // (kSym64: the word is made opaque so that every test is one s_bitcmp on it; as boolean values the compiler keeps
     // them as 64-bit lane masks and spends a v_cndmask / v_cmp pair on each negation)
     int epi_word = epi_flags;
-    if (!kTrace && SYM && EPI && MODE != kRollout) asm volatile("" : "+s"(epi_word));
+    if (!kTrace && SYM && EPI && !is_rollout(MODE)) asm volatile("" : "+s"(epi_word));
 #define has_acc (EPI && (epi_word & 1) != 0)
 #define auto_reset (EPI && (epi_word & 2) != 0)
-    const bool rand_act = EPI && MODE == kRollout && (epi_flags & 4) != 0;
+    const bool rand_act = MODE == kRolloutRand ? true : MODE == kRolloutPool ? false : (EPI && is_rollout(MODE) && (epi_flags & 4) != 0);
     // the 32 hot bytes of the env's record live in registers for the whole launch, split over two lanes so that one
     // load and one store instruction move them: agent 0 holds (ep_return, ep_true_return) as two doubles, agent 1
     // holds (ep_collisions, ep_len, episodes, reserved) as four ints
@@ -617,7 +623,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     g_u32x4 *o_acc = (g_u32x4 *)(a.acc + 8 * (size_t)(SYM ? env0 : 0));
     // (kSym64 only for now: the workgroup-per-env kernels of the episode layer sit at 85 scalar registers without them;
     // not the fused rollout with the episode layer either, which is at its register limits as it is)
-    constexpr bool PIN = !kTrace && SYM && !(MODE == kRollout && EPI);   // (the trace build's stamps make hipcc lose the uniformity)
+    constexpr bool PIN = !kTrace && SYM && !(is_rollout(MODE) && EPI && MODE != kRolloutPool);   // (the trace build's stamps make hipcc lose the uniformity)
     if (PIN && MODE != kObserve)
         asm volatile("" : "+s"(o_reward), "+s"(o_true), "+s"(o_pos), "+s"(o_vel), "+s"(o_gz), "+s"(o_gn),
                           "+s"(k_q), "+s"(k_b), "+s"(k_ghost), "+s"(k_done_radius), "+s"(k_last_t));
@@ -675,7 +681,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
 
     // (Delta_j, l_j) of a partner: kernel-argument scalars when all agents share them -- except in the fused
     // rollout, whose register budget is tighter (there the LDS table is the cheaper source)
-    const bool uni_args = SYM || BU || (MODE != kRollout && uniform);   // (kSym64: always uniform; scalar registers cost it nothing)
+    const bool uni_args = SYM || BU || (!is_rollout(MODE) && uniform);   // (kSym64: always uniform; scalar registers cost it nothing)
     if (WL) {
         if (!SYM && (int)lane < 2 * a.P) sred[2 * wave * a.P + lane] = 0;   // kSym64 keeps these verdicts in scalar registers
         if (!uni_args && (int)lane < N)
@@ -687,12 +693,12 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 sconst[s] = uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[s], a.radius[s]);
     }
 
-    if (SYM && MODE != kRollout) { sbx[lane] = 0ull; sby[lane] = 0ull; }   // (the fused rollout zeroes them per rebuild)
+    if (SYM && !is_rollout(MODE)) { sbx[lane] = 0ull; sby[lane] = 0ull; }   // (the fused rollout zeroes them per rebuild)
     // Workgroup-per-env, single step: the cell tables are zeroed HERE and the barrier that orders the zeroing (and the
     // words above) against the other waves' atomics is taken in the shadow of the state loads -- an LDS-only barrier
     // (__syncthreads() carries a release fence, i.e. a vmcnt(0) wait for the loads in flight).  One barrier instead of
     // two, and no zeroing loop, between the loads' return and the first mask read.
-    constexpr bool EARLY_TABLES = BLOCKGEO && MODE != kRollout;
+    constexpr bool EARLY_TABLES = BLOCKGEO && !is_rollout(MODE);
     if (EARLY_TABLES) {
         for (int o = tid; o < 2 * kCells * W; o += blockDim.x) sbt_all[o] = 0ull;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -704,7 +710,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     float2 *spos_env = SYM ? reinterpret_cast<float2 *>(sym_block) : spos + (size_t)slot * 2 * stride;   // S0 of this lane's env
     // pass-1 window of this lane starts at dup index agent + (odd r): pick the copy where that is even
     const float2 *pwin = (agent & 1) ? spos_env + agent + 1 : spos_env + stride + agent + 2;
-    const int nsteps = (MODE == kRollout) ? a.T : 1;
+    const int nsteps = (is_rollout(MODE)) ? a.T : 1;
     // c = 5 rows carry (v, l) of tie-ordered agents, which forces the FAR variant on the host: every other
     // instantiation knows c = 2 at compile time (no dead c = 5 code, and no conservative s_waitcnt for its loads)
     const int zc = FAR ? a.c : 2;
@@ -720,9 +726,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // exact test in pass 2.
     // (round 3: also the workgroup-per-env rollout of up to 256 agents, CACHED_B -- same list, one 64-bit word per 64
     // partners, the "somebody moved" verdict agreed through an LDS word at the step's first barrier)
-    constexpr bool CACHED_B = B256 && MODE == kRollout && !FAR;
+    constexpr bool CACHED_B = B256 && is_rollout(MODE) && !FAR;
     // (not for FAR: its far tail needs the EXACT near set, and a listed-but-currently-far partner is not in it)
-    constexpr bool CACHED = (SYM && !FAR && MODE == kRollout) || CACHED_B;
+    constexpr bool CACHED = (SYM && !FAR && is_rollout(MODE)) || CACHED_B;
     const float thr_list = CACHED ? (reach + a.skin) * (reach + a.skin) * 1.000001f : thr;
     const float moved2 = 0.49f * a.skin * 0.49f * a.skin;
     const float inv_cell = __builtin_amdgcn_rcpf((CACHED ? (SYM ? reach : a.reach_max) + a.skin : a.reach_max) * 1.001f);   // bucket filter: cells a little wider than the list radius
@@ -785,13 +791,13 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // with pool actions and the episode layer goes from 2.46 to 2.72 us per step (same A/B, profiles/r4_abtest_rollout_pin.log)
     // (a plain `s_waitcnt vmcnt(0)` builtin on the rand_act side instead of the operand pin does not clear the
     // compiler's view of the pending loads: no gain)
-    if (MODE == kRollout && (SYM || !rand_act))
+    if (is_rollout(MODE) && (SYM || !rand_act))
         asm volatile("" : : "v"(xi), "v"(yi), "v"(u0.x), "v"(u0.y), "v"(xFx), "v"(xFy), "v"(xLx), "v"(xLy), "v"(dhat), "v"(delta_i),
                      "v"(li), "v"(tcur), "v"(epi), "v"(accw.x), "v"(accw.y), "v"(accw.z), "v"(accw.w));
     float2 unext = make_float2(0.f, 0.f);                    // fused rollout: the next step's action, in flight
     // @phase integrate
     for (int step = 0; step < nsteps; ++step) {
-        const size_t so = (MODE == kRollout) ? (size_t)step * step_agents : 0;   // output offset (agents)
+        const size_t so = (is_rollout(MODE)) ? (size_t)step * step_agents : 0;   // output offset (agents)
         const float *velsrc = (MODE == kObserve) ? a.vel : a.act + 2 * so;       // v of other agents
         if (rand_act) {
             // RandomAgent.forward (SAC_agents.py:9-22) drawn in place: one Philox block serves the steps t and t + 1
@@ -816,14 +822,14 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         // the allocator places elsewhere is copied -- and waited for -- right behind the request)
         // (the packed geometry keeps the round-2 form, prefetch under `valid` straight into u0: at its 128-register cap
         // the separate pair is itself copied and waited for at once -- C2 +5 %)
-        constexpr bool PREFETCH_SEP = MODE == kRollout && GEO != kPacked;
+        constexpr bool PREFETCH_SEP = is_rollout(MODE) && GEO != kPacked;
         if (PREFETCH_SEP && !rand_act && step > 0) u0 = unext;
         const float2 u = u0;
         if (PREFETCH_SEP && !rand_act && step + 1 < nsteps) {
             const float2 *nxt = reinterpret_cast<const float2 *>(a.act) + (nval > 0 ? so + step_agents + wga0 : 0);
             unext = nxt[valid ? lane : 0u];
         }
-        if (MODE == kRollout && !PREFETCH_SEP && !rand_act && valid && step + 1 < nsteps)
+        if (is_rollout(MODE) && !PREFETCH_SEP && !rand_act && valid && step + 1 < nsteps)
             u0 = (reinterpret_cast<const float2 *>(a.act) + so + step_agents + wga0)[lane];
         if (valid) {
             if (MODE != kObserve) {
@@ -1110,7 +1116,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     //     candidates = (x masks) & (y masks).  Coordinates beyond the 64 cells clamp to the end
                     //     cells, which only ever adds candidates.  ~35 instructions instead of 32 offsets x 5+.
                     const unsigned long long self = self_bit;
-                    if (CACHED || MODE == kRollout) { sbx[lane] = 0ull; sby[lane] = 0ull; }   // (step / observe: zeroed ahead of the loads' return)
+                    if (CACHED || is_rollout(MODE)) { sbx[lane] = 0ull; sby[lane] = 0ull; }   // (step / observe: zeroed ahead of the loads' return)
                     const int cx = (int)fminf(fmaxf(fmaf(xi, inv_cell, 1.0f), 1.0f), 62.0f);
                     const int cy = (int)fminf(fmaxf(fmaf(yi, inv_cell, 1.0f), 1.0f), 62.0f);
                     group_sync<true>();
@@ -1291,7 +1297,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         unsigned long long outside_m = 0ull;                  //         disk, wave-uniform (scalar registers)
         // fused rollout: the next step's action (prefetched at the top of this step) is waited for HERE, ahead of the
         // step's first output store -- at the loop's end the same wait would also cover the stores just issued
-        if (MODE == kRollout && GEO != kPacked) asm volatile("" : "+v"(unext.x), "+v"(unext.y));
+        if (is_rollout(MODE) && GEO != kPacked) asm volatile("" : "+v"(unext.x), "+v"(unext.y));
         if (valid) {
             TRACE_MARK(3);
             // rewards (:276, :287-288)
@@ -1389,7 +1395,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
 
             // @phase epilogue_state_done
             if (MODE != kObserve) {
-                if (MODE != kRollout || step == nsteps - 1) {                 // final state only
+                if (!is_rollout(MODE) || step == nsteps - 1) {                 // final state only
                     st_g2(o_pos + 2 * lane, xi, yi);
                     st_g2(o_vel + 2 * lane, vxi, vyi);
                 }
@@ -1504,7 +1510,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             }
             const int coll_env = red.x;
             if (agent == 0) {
-                const size_t eo = (MODE == kRollout) ? (size_t)step * a.E + env : (size_t)env;
+                const size_t eo = (is_rollout(MODE)) ? (size_t)step * a.E + env : (size_t)env;
                 if (a.n_coll) a.n_coll[eo] = coll_env;
                 bool fin = false;
                 if (MODE != kObserve) {
@@ -1553,6 +1559,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 any_rs = WL ? (__builtin_amdgcn_ballot_w64(rs) != 0ull) : (__builtin_amdgcn_readfirstlane((int)flag) != 0);
             }
             if (__builtin_expect(any_rs, 0)) {                // once per episode and env: out of line
+                // (`s_nop 13` ... `s_nop 14`: where this cold block begins and ends in the ISA, for tools/spill_sites.py --
+                // which scratch accesses of an episode-layer kernel sit on the per-step path and which in here)
+                asm volatile("s_nop 13");
                 // This block's own kernel arguments are read through the kernel-argument segment behind an opaque pointer,
                 // and its per-lane addresses are formed from an opaque copy of the lane id: read as fields of `a` / formed
                 // from `lane`, the compiler hoists those scalar loads and 64-bit additions in front of the branch, i.e.
@@ -1749,14 +1758,15 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                             st_out2(row, rx, ry);
                         }
                     }
-                    if (MODE != kRollout || step == nsteps - 1) {
+                    if (!is_rollout(MODE) || step == nsteps - 1) {
                         st_g2(o_pos + 2 * lane_c, xi, yi);
                         st_g2(o_vel + 2 * lane_c, 0.f, 0.f);
                     }
                 }
+                asm volatile("s_nop 14");
             }
         }
-        if (MODE == kRollout) {
+        if (is_rollout(MODE)) {
             group_sync<WL>();                                 // staging / sred reuse by the next step
             p_reward += step_agents; p_true += step_agents;
             p_gz += step_agents * kZRow; p_gn += step_agents * kNRow;
@@ -1830,7 +1840,12 @@ hipError_t launch_mode(int mode, const KArgs &a, const Geometry &g, hipStream_t 
     switch (mode) {
     case kStep: return epi ? launch_one<K, FAR, kStep, GEO, true>(a, g, s) : launch_one<K, FAR, kStep, GEO, false>(a, g, s);
     case kObserve: return launch_one<K, FAR, kObserve, GEO, false>(a, g, s);
-    default: return epi ? launch_one<K, FAR, kRollout, GEO, true>(a, g, s) : launch_one<K, FAR, kRollout, GEO, false>(a, g, s);
+    default:
+        if (!epi) return launch_one<K, FAR, kRollout, GEO, false>(a, g, s);
+        if constexpr (GEO == kSym64)   // the action source at compile time (see Mode)
+            return a.rand_act ? launch_one<K, FAR, kRolloutRand, GEO, true>(a, g, s) : launch_one<K, FAR, kRolloutPool, GEO, true>(a, g, s);
+        else
+            return launch_one<K, FAR, kRollout, GEO, true>(a, g, s);
     }
 }
 
@@ -1845,7 +1860,8 @@ hipError_t launch_k(int mode, bool far, const KArgs &a, const Geometry &g, hipSt
         return far ? launch_mode<K, true, kBlock256>(mode, a, g, s) : launch_mode<K, false, kBlock256>(mode, a, g, s);
     case kBlockU256: {                              // rollouts only (launch() picks it for mode == kRollout)
         const bool epi = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;
-        return epi ? launch_one<K, false, kRollout, kBlockU256, true>(a, g, s) : launch_one<K, false, kRollout, kBlockU256, false>(a, g, s);
+        if (epi) return a.rand_act ? launch_one<K, false, kRolloutRand, kBlockU256, true>(a, g, s) : launch_one<K, false, kRolloutPool, kBlockU256, true>(a, g, s);
+        return launch_one<K, false, kRollout, kBlockU256, false>(a, g, s);
     }
     default:
         return far ? launch_mode<K, true, kBlock1024>(mode, a, g, s) : launch_mode<K, false, kBlock1024>(mode, a, g, s);

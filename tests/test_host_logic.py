@@ -299,15 +299,17 @@ def test_no_rollout_kernel_spills_on_its_hot_path():
     lib = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "libdronesim.so")
     for geo in (0, 1, 2, 4):
         for epi in (0, 1):
-            r = SS.hot_loop_scratch(lib, 2, 0, 2, geo, epi)
-            assert r is not None, (geo, epi)
-            n_ins, loop, hot, total = r
-            assert loop is not None and loop[1] - loop[0] > 500, (geo, epi, loop)      # the per-step loop was found
-            assert hot == 0, f"GEO={geo} EPI={epi}: {hot} scratch instructions inside the per-step loop {loop}"
-            if geo in (1, 4) and epi == 0:
-                assert total == 0, (geo, epi, total)
-    # kSym64 with the episode layer (bench.py's fused_rollout line): no scratch anywhere
-    assert SS.hot_loop_scratch(lib, 2, 0, 2, 1, 1)[3] == 0
+            # (kSym64 / kBlockU256 with the episode layer: one kernel per action source, MODE 3 = pool, 4 = in-kernel)
+            for mode in ((3, 4) if (epi and geo in (1, 4)) else (2,)):
+                r = SS.hot_loop_scratch(lib, 2, 0, mode, geo, epi)
+                assert r is not None, (geo, epi, mode)
+                n_ins, loop, hot, total = r
+                assert loop is not None and loop[1] - loop[0] > 500, (geo, epi, mode, loop)      # the per-step loop was found
+                assert hot == 0, f"GEO={geo} EPI={epi} MODE={mode}: {hot} scratch instructions inside the per-step loop {loop}"
+                if geo in (1, 4) and epi == 0:
+                    assert total == 0, (geo, epi, total)
+                if geo == 1:                                  # kSym64 (bench.py's fused_rollout lines): no scratch anywhere
+                    assert total == 0, (geo, epi, mode, total)
 
 
 def test_policy_kernels_keep_their_occupancy():

@@ -73,7 +73,8 @@ if __name__ == "__main__":
 
 def hot_loop_scratch(lib, K, FAR, MODE, GEO, EPI):
     """(instructions, (start, end) of the largest loop by layout = the per-step loop of a fused rollout, scratch
-    instructions inside it, scratch instructions in all) for one drone_kernel instantiation, or None if absent."""
+    instructions inside it but outside the out-of-line in-kernel reset, scratch instructions in all) for one
+    drone_kernel instantiation, or None if absent."""
     pat = f"drone_kernelILi{K}ELb{FAR}ELi{MODE}ELi{GEO}ELb{EPI}E"
     for name, ins in disasm(lib, pat):
         addr = {a: i for i, (a, _) in enumerate(ins)}
@@ -91,5 +92,12 @@ def hot_loop_scratch(lib, K, FAR, MODE, GEO, EPI):
             return len(ins), None, 0, sum(t.startswith("scratch_") for _, t in ins)
         s, e = max(loops, key=lambda l: l[1] - l[0])
         sc = [i for i, (_, t) in enumerate(ins) if t.startswith("scratch_")]
-        return len(ins), (s, e), sum(s <= i <= e for i in sc), len(sc)
+        # the out-of-line in-kernel reset of the episode layer is bracketed by `s_nop 13` / `s_nop 14` in the source
+        cb = [i for i, (_, t) in enumerate(ins) if re.fullmatch(r"s_nop 13", t)]
+        ce = [i for i, (_, t) in enumerate(ins) if re.fullmatch(r"s_nop 14", t)]
+        # (a block laid out behind the loop ends with the jump back to the loop header: its end marker then sits at the top
+        # of the loop, BEFORE the begin marker in layout order -- the block runs to the end of the function)
+        cold = None if not cb else (min(cb), max(ce)) if ce and min(cb) < max(ce) else (min(cb), len(ins))
+        hot = [i for i in sc if s <= i <= e and not (cold and cold[0] <= i <= cold[1])]
+        return len(ins), (s, e), len(hot), len(sc)
     return None
