@@ -384,12 +384,16 @@ constexpr int kBlockStepWavesEpi = 6;      // (8 makes the episode-layer kernels
 // after an in-kernel reset still walked one exec-masked loop per word -- see the cold path; tests/test_gpu_fuzz.py and
 // test_rollout_with_pool_actions_equals_steps_across_resets guard it.)
 constexpr int kBlockRolloutEpiWaves = 4;
-// Round 5: the packed and the general workgroup-per-env rollouts of the episode layer (run-time choice of pool / in-kernel
-// actions, records, in-kernel reset: all of it live across the per-step loop) spilled 18-21 registers INSIDE the loop at
-// the 128-register budget; at 3 waves per SIMD (168 registers) the loop is spill-free (tests/test_host_logic.py:
-// test_no_rollout_kernel_spills_on_its_hot_path).  kBlockU256 (N = 256, uniform constants: BASELINE configs[4]) keeps
-// 4: its loop holds no spill at 128 registers (only the out-of-line reset does).
-constexpr int kRolloutEpiWaves = 3;
+// Round 5: the packed rollout of the episode layer (run-time choice of pool / in-kernel actions, records, in-kernel reset:
+// all of it live across the per-step loop) spilled 21 registers INSIDE the loop at the 128-register budget; at 3 waves
+// per SIMD (168 registers) the loop is spill-free and C2's rollout runs 2.97 -> 2.54 us per step, 5 x 65536 envs
+// 10.5 -> 7.5 (profiles/r5_abtest_rollout_epi_waves.log; tests/test_host_logic.py:
+// test_no_rollout_kernel_spills_on_its_hot_path).  The general workgroup-per-env rollout (65 ... 255 agents, or N = 256
+// with non-uniform constants) was measured the same way and KEEPS 4: spill-free at 168 registers it is 3 ... 13 % SLOWER
+// (N = 128 x 4096 envs 8.62 -> 8.91 us, with in-kernel actions 8.15 -> 9.26; N = 200 x 2048 envs 7.23 -> 7.99) -- its 18
+// scratch accesses per step cost less than the fourth wave per SIMD.  kBlockU256 (N = 256, uniform constants: BASELINE
+// configs[4]) holds no spill in its loop at 128 registers (only the out-of-line reset does).
+constexpr int kPackedRolloutEpiWaves = 3;
 
 template <int GEO> struct GeoTraits {
     static constexpr int kMaxThreads = GEO == kBlock1024 ? 1024 : 256;
@@ -406,7 +410,7 @@ template <int GEO> struct GeoTraits {
         const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && !is_rollout(mode)) ? kSymStepWaves
                                                                           : ((GEO == kBlock256 || GEO == kBlockU256) && !is_rollout(mode)) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
                                      : (GEO == kBlockU256 && epi) ? kBlockRolloutEpiWaves
-                                     : ((GEO == kBlock256 || GEO == kPacked) && epi && !far) ? kRolloutEpiWaves : 4;
+                                     : (GEO == kPacked && epi && !far) ? kPackedRolloutEpiWaves : 4;
         const int cap = k <= 2 ? 8 : k <= 4 ? (((far || epi) && GEO == kBlock256 && !is_rollout(mode)) ? 5 : 6) : 4;   // (k = 3 / 4, FAR or episode layer: 8-12 B of spills at 80 registers)
         return want < cap ? want : cap;
     }
@@ -623,7 +627,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     g_u32x4 *o_acc = (g_u32x4 *)(a.acc + 8 * (size_t)(SYM ? env0 : 0));
     // (kSym64 only for now: the workgroup-per-env kernels of the episode layer sit at 85 scalar registers without them;
     // not the fused rollout with the episode layer either, which is at its register limits as it is)
-    constexpr bool PIN = !kTrace && SYM && !(is_rollout(MODE) && EPI && MODE != kRolloutPool);   // (the trace build's stamps make hipcc lose the uniformity)
+    // (round 5, with the action source at compile time: the pool-action rollout WITH the pins measured the same as without,
+    // 3.19 us per step at C3, at 120 instead of 113 registers: profiles/r5_abtest_rollout_action_source.log)
+    constexpr bool PIN = !kTrace && SYM && !(is_rollout(MODE) && EPI);   // (the trace build's stamps make hipcc lose the uniformity)
     if (PIN && MODE != kObserve)
         asm volatile("" : "+s"(o_reward), "+s"(o_true), "+s"(o_pos), "+s"(o_vel), "+s"(o_gz), "+s"(o_gn),
                           "+s"(k_q), "+s"(k_b), "+s"(k_ghost), "+s"(k_done_radius), "+s"(k_last_t));

@@ -846,8 +846,12 @@ int dronesim_returns(const float *reward, const uint8_t *done, float gamma, floa
     if (!reward || !G || T < 0 || E < 0 || N < 1) return fail(DRONESIM_EINVAL, "dronesim_returns: bad argument");
     if (T == 0 || E == 0) return DRONESIM_OK;
     const size_t cols = (size_t)E * N;
-    // 16-byte columns quadruples when every row of the [T][E N] arrays starts 16-byte aligned and an env's agents come in fours
-    const bool v4 = (N % 4) == 0 && ((reinterpret_cast<uintptr_t>(reward) | reinterpret_cast<uintptr_t>(G)) & 15u) == 0;
+    // 16-byte column quadruples when every row of the [T][E N] arrays starts 16-byte aligned, an env's agents come in fours
+    // and the quadruples still fill the chip: below one wave per SIMD (1024 x 64 x 4 columns) half the SIMDs idle -- T = 200 x
+    // 512 x 256: 38.6 us with one column per thread, 45.6 with four --, at C3's 262144 columns four per thread win (78.1 ->
+    // 69.8 us: 0.75 of the roofline), from a million columns up one per thread is 3 % ahead again (profiles/r5_retbench.log)
+    const bool v4 = (N % 4) == 0 && ((reinterpret_cast<uintptr_t>(reward) | reinterpret_cast<uintptr_t>(G)) & 15u) == 0 &&
+                    cols >= 262144 && cols < 1048576;
     if (v4)
         hipLaunchKernelGGL(returns_kernel<4>, dim3((unsigned)((cols / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                            reward, done, gamma, G, T, E, N);

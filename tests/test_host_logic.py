@@ -286,11 +286,12 @@ def test_no_step_kernel_spills():
 
 
 def test_no_rollout_kernel_spills_on_its_hot_path():
-    """Fused rollouts (MODE = 2) of the BUILT library at k = 2 without far agents -- every BASELINE shape: kPacked (C2),
-    kSym64 (C3 / C4), kBlockU256 (C5), and kBlock256 (65 ... 255 agents) -- with and without the episode layer: NO scratch
-    instruction inside the per-step loop (tools/spill_sites.py: the largest loop of the ISA by layout).  What scratch an
-    episode-layer kernel does use sits in the out-of-line in-kernel reset (once per episode and env), laid out behind
-    the loop; the plain kernels of the one-env-per-wave and N = 256 geometries use none at all."""
+    """Fused rollouts of the BUILT library at k = 2 without far agents for every BASELINE shape -- kPacked (C2), kSym64
+    (C3 / C4), kBlockU256 (C5) -- with and without the episode layer, and the plain kBlock256 (65 ... 255 agents): NO scratch
+    instruction on the per-step path (tools/spill_sites.py: inside the largest loop of the ISA, outside the out-of-line
+    in-kernel reset that `s_nop 13` / `s_nop 14` bracket).  What scratch an episode-layer kernel does use sits in that
+    reset (once per episode and env).  (kBlock256 WITH the episode layer keeps 18 scratch accesses per step on purpose:
+    spill-free at 168 registers it measured 3 ... 13 % slower -- csrc/drone_kernel.hpp, kPackedRolloutEpiWaves.)"""
     import shutil
     from tools import kernel_resources as KR
     from tools import spill_sites as SS
@@ -298,7 +299,7 @@ def test_no_rollout_kernel_spills_on_its_hot_path():
         pytest.skip("llvm-readelf not available")
     lib = os.path.join(os.path.dirname(os.path.abspath(pkg.__file__)), "libdronesim.so")
     for geo in (0, 1, 2, 4):
-        for epi in (0, 1):
+        for epi in ((0,) if geo == 2 else (0, 1)):
             # (kSym64 / kBlockU256 with the episode layer: one kernel per action source, MODE 3 = pool, 4 = in-kernel)
             for mode in ((3, 4) if (epi and geo in (1, 4)) else (2,)):
                 r = SS.hot_loop_scratch(lib, 2, 0, mode, geo, epi)
