@@ -40,7 +40,8 @@
 extern "C" {
 #endif
 
-#define DRONESIM_VERSION 500           /* 0.5.0: the float64 verification entry points moved to libdronesim_verify.so (dronesim_verify.h) */
+#define DRONESIM_VERSION 500           /* 0.5.0: the float64 verification entry points moved to libdronesim_verify.so (dronesim_verify.h);
+                                          DroneMlpBf16.wscale */
 #define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
 #define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
 
@@ -314,6 +315,13 @@ typedef struct DroneMlpBf16 {
     int32_t N, d_in, h1, h2, nout, out_kind, sample_kind, reserved;
     const void *w1p, *w2p, *w3p;     /* packed bf16 fragments */
     const float *b1, *b2, *b3;       /* [N][h1], [N][h2], [N][nout] float32 */
+    /* dronesim_mlp_forward_f16x2 only (NULL = all ones; ignored by the other entry points): [N][3] float32, POWERS OF TWO.
+     * wscale[i][l] says that the packed image of layer l of agent i holds the weights MULTIPLIED by wscale[i][l] before
+     * they were split; the kernel multiplies the layer's accumulators by 1 / wscale[i][l] (exact) before the bias-free
+     * part meets the next layer.  A float16 part below 2^-14 is subnormal and keeps an ABSOLUTE 2^-24: an unscaled weight
+     * of 0.05 is represented to 6e-7 of itself instead of 2^-22, which large activations multiply -- scaled so that the
+     * layer's largest weight sits near 2^14, every weight keeps its 22 bits (round 5).                              */
+    const float *wscale;
 } DroneMlpBf16;
 int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                               uint64_t seed, uint64_t counter, int64_t env_base,
@@ -339,9 +347,9 @@ int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *ou
 /* The same with a two-part float16 split ("f16x2"): v = hi + lo with hi = float16(v), lo = float16(v - hi), exact to
  * 2^-22 of v (the float16 matrix instruction honours subnormal parts), and a product is the float32 sum of hi*hi,
  * hi*lo, lo*hi (the rest is below 2^-22 of the product): float32-level agreement with dronesim_mlp_forward (same 1e-5
- * bar) at 3/16 of its matrix time and 2/3 of the weight bytes of bf16x3.  DOMAIN: every weight, input and hidden
- * activation must be below 65504 in magnitude (float16 range) -- beyond it the result is inf / NaN; use bf16x3 or
- * dronesim_mlp_forward for such networks.  Weight image as for bf16x3 with two float16 parts per stage:
+ * bar) at 3/16 of its matrix time and 2/3 of the weight bytes of bf16x3.  DOMAIN: every (scaled, see
+ * DroneMlpBf16.wscale) weight, input and hidden activation must be below 65504 in magnitude (float16 range) -- beyond
+ * it the result is inf / NaN; use bf16x3 or dronesim_mlp_forward for such networks.  Weight image as for bf16x3 with two float16 parts per stage:
  * [N][4][S][2][64][8] float16, 2 KiB per stage.  */
 int dronesim_mlp_forward_f16x2(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                                uint64_t seed, uint64_t counter, int64_t env_base,

@@ -87,7 +87,7 @@ class DroneMlpBf16(C.Structure):
     _fields_ = [("N", C.c_int32), ("d_in", C.c_int32), ("h1", C.c_int32), ("h2", C.c_int32), ("nout", C.c_int32),
                 ("out_kind", C.c_int32), ("sample_kind", C.c_int32), ("reserved", C.c_int32),
                 ("w1p", C.c_void_p), ("w2p", C.c_void_p), ("w3p", C.c_void_p),
-                ("b1", C.c_void_p), ("b2", C.c_void_p), ("b3", C.c_void_p)]
+                ("b1", C.c_void_p), ("b2", C.c_void_p), ("b3", C.c_void_p), ("wscale", C.c_void_p)]
 
 
 class DroneSimError(RuntimeError):

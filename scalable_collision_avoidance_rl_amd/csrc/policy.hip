@@ -59,33 +59,7 @@ struct MArgs {
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     FinishArgs fin;
     long long *trace;                    // developer trace builds only (NULL otherwise)
-    int half_tail;                       // transposed path: a last chunk of <= 16 features is its own K-split piece (see tr_plan)
 };
-
-// Transposed path (packed W2, nout <= 16): how the 32-column chunks of layer 2 are dealt to the four waves of a workgroup.
-//   H        the last chunk holds <= 16 features: computed on the 16-column matrix instruction at half the matrix time,
-//            its K range split over the four waves (h = 400: 16 features, h = 300: 12, h = 200: 8)
-//   nwhole   full chunks dealt whole, wave w taking w, w + 4, ...: whole rounds of four, or everything when THREE full
-//            chunks are left over (three K-split pieces per wave cost more in pipeline ramps than the idle wave)
-//   L        1 or 2 leftover full chunks, split by K over the four waves / two pairs of waves
-// The leftover pieces of a wave (at most two: its part of a full chunk and its part of H) are computed back to back into
-// partial tiles of their own, ONE barrier later one wave per chunk adds the partials in a fixed order and feeds layer 3.
-// Round 4 knew one kind of leftover trip per network: h = 300 ran its 12-column tail as a full 32-column tile next to the
-// ninth full chunk (two pairs: 10 stages per wave for 7.1 of work), h = 200 dealt 7 chunks whole (2, 2, 2, 1: the 8-column
-// tail as a full tile again): 0.64 / 0.48 of the matrix peak against 0.73 at h = 400.
-struct TrPlan { int hasH, L, nwhole, rounds, np; };
-__host__ __device__ __forceinline__ TrPlan tr_plan(int h2, int half_tail)
-{
-    TrPlan t;
-    const int nch = (h2 + 31) >> 5;
-    t.hasH = (half_tail && h2 - 32 * (nch - 1) <= 16) ? 1 : 0;
-    const int nfull = nch - t.hasH;
-    t.L = (nfull & 3) == 3 ? 0 : (nfull & 3);
-    t.nwhole = nfull - t.L;
-    t.rounds = (t.nwhole + 3) >> 2;
-    t.np = (t.L ? 1 : 0) + t.hasH;
-    return t;
-}
 
 // LDS row stride (floats) of the h1 tile for the packed layer 2: whole 32-column chunks (the k padding is written as
 // zeros by layer 1), a multiple of 4 (16-byte aligned rows) whose quotient is odd (ds_read_b128 phases conflict-free)
@@ -527,115 +501,6 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
     f32x4 yn[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
     float *st = sst + wave * 32 * kSt;
     const int nch = (a.h2 + 31) >> 5;
-    if (TR) {
-        // ---- transposed path: whole chunks, then this wave's K parts of the leftover chunks, then (one barrier later) the
-        // finishing of the leftover chunks -- see tr_plan.  One loop, one inlined copy of each GEMM form and of layer 3.
-        const TrPlan tp = tr_plan(a.h2, a.half_tail);
-        const int kpad = 16 * nst;
-        for (int it = 0; it < tp.rounds + 2 * tp.np; ++it) {        // wave-uniform trip count (a barrier inside)
-            const int ph = it < tp.rounds ? 0 : it < tp.rounds + tp.np ? 1 : 2;   // whole chunk | K part of a leftover chunk | finishing one
-            const int p = ph == 0 ? 0 : (it - tp.rounds) - (ph == 2 ? tp.np : 0);   // piece slot of this wave
-            const bool isH = ph != 0 && tp.hasH && p == tp.np - 1;  // the <= 16-feature tail chunk on the 16-column instruction
-            const int split = (isH || tp.L != 2) ? 4 : 2;           // waves sharing the chunk
-            const int part = cw & (split - 1);                      // this wave's K part
-            const int chunk = ph == 0 ? cw + 4 * it : isH ? nch - 1 : tp.nwhole + (tp.L == 2 ? cw >> 1 : 0);
-            const int c0 = chunk * 32;
-            if (ph == 0 && chunk >= tp.nwhole) continue;            // ragged last round of the whole dealing
-            float *reg = sst + (p * 4 + wave) * 32 * kSt;           // this wave's tile of piece slot p (slot 0: its whole chunks too)
-            bool l3 = false;                                        // this wave feeds the chunk to layer 3 in this trip
-            if (ph == 2) {
-                if (p == 0) __syncthreads();                        // every partial tile of every leftover chunk is in LDS
-                // one wave per chunk adds the partials in a fixed order: a full chunk's first wave (its part 0), the tail
-                // chunk's wave 1 when wave 0 is busy with a full chunk
-                const int wbase = split == 2 ? (cw & 2) : 0;        // first wave of the group that shares the chunk
-                const bool mine = isH ? cw == (tp.L ? 1 : 0) : part == 0;
-                if (mine) {
-                    const float *r0 = sst + (p * 4 + wbase) * 32 * kSt;
-                    if (isH) {
-                        const int i16 = lane & 15, g4 = lane >> 4;
-#pragma unroll
-                        for (int rt = 0; rt < 2; ++rt) {
-                            const int o = (rt * 16 + i16) * kSt + 4 * g4;
-                            const f32x4 *q0 = reinterpret_cast<const f32x4 *>(r0 + o);
-                            f32x4 v = ((q0[0] + q0[32 * kSt / 4]) + q0[2 * 32 * kSt / 4]) + q0[3 * 32 * kSt / 4];
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
-                            *reinterpret_cast<f32x4 *>(reg + o) = v;
-                            *reinterpret_cast<f32x4 *>(reg + o + 16) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // features 16 .. 31 read as zero in layer 3
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int o = col * kSt + 8 * q + 4 * (lane >> 5);
-                            const f32x4 *q0 = reinterpret_cast<const f32x4 *>(r0 + o);
-                            f32x4 v = q0[0] + q0[32 * kSt / 4];
-                            if (split == 4) v = (v + q0[2 * 32 * kSt / 4]) + q0[3 * 32 * kSt / 4];
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) v[t] = fmaxf(v[t], 0.0f);
-                            *reinterpret_cast<f32x4 *>(reg + o) = v;
-                        }
-                    }
-                    l3 = true;
-                }
-            } else {
-                const bool left = ph == 1;
-                const int kq = 16 * ((nst + split - 1) / split);    // 1 / split of K, whole stages
-                const int kb = left ? min(part * kq, kpad) : 0, kn = left ? min(kq, kpad - kb) : kpad;
-                if (isH) {
-                    // D[16 features][16 rows] x two row tiles x 4 k per step = 8 instructions of 32 cycles per 16 k instead of 8 of
-                    // 64 on a tile whose other 16 feature rows are padding.  Lane (i = lane & 15, g = lane >> 4) takes
-                    // k = 16 s + 4 g + t at step t of stage s: its four weights are ONE 16-byte piece of the chunk's ordinary packed
-                    // stage ([q = g & 1][lane i + 32 (g >> 1)]: no other layout needed), its four h1 values one ds_read_b128 per row tile.
-                    const int i16 = lane & 15, g4 = lane >> 4;
-                    const f32x4 *Wp = reinterpret_cast<const f32x4 *>(w2 + (size_t)chunk * nst * 512) + (g4 & 1) * 64 + i16 + 32 * (g4 >> 1);
-                    const float *hr0 = sh1 + i16 * ld1 + 4 * g4, *hr1 = hr0 + 16 * ld1;
-                    const float bh = (part == 0 && c0 + i16 < a.h2) ? b2[c0 + i16] : 0.0f;
-                    f32x4 ha[2] = {{0.0f, 0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f, 0.0f}};
-                    const int s0 = kb >> 4, sn = kn >> 4;
-                    if (sn > 0) {
-                        f32x4 wv = Wp[(size_t)s0 * 128];
-                        f32x4 x0 = *reinterpret_cast<const f32x4 *>(hr0 + 16 * s0), x1 = *reinterpret_cast<const f32x4 *>(hr1 + 16 * s0);
-                        for (int s1 = 0; s1 < sn; ++s1) {
-                            const int sx2 = s0 + min(s1 + 1, sn - 1);                 // next stage (the last one re-reads itself: no branch)
-                            const f32x4 wn = Wp[(size_t)sx2 * 128];
-                            const f32x4 y0 = *reinterpret_cast<const f32x4 *>(hr0 + 16 * sx2), y1 = *reinterpret_cast<const f32x4 *>(hr1 + 16 * sx2);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                ha[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], x0[t], ha[0], 0, 0, 0);
-                                ha[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[t], x1[t], ha[1], 0, 0, 0);
-                            }
-                            wv = wn; x0 = y0; x1 = y1;
-                        }
-                    }
-                    if (part == 0) {                                 // bias on the matrix pipe (k slot of lanes 0..15), as in bias_mfma
-#pragma unroll
-                        for (int rt = 0; rt < 2; ++rt)
-                            ha[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(g4 == 0 ? bh : 0.0f, g4 == 0 ? 1.0f : 0.0f, ha[rt], 0, 0, 0);
-                    }
-                    // D: register r of lane (i, g) = (feature 4 g + r, row 16 rt + i) -> this wave's partial tile [row][feature]
-#pragma unroll
-                    for (int rt = 0; rt < 2; ++rt) *reinterpret_cast<f32x4 *>(reg + (rt * 16 + i16) * kSt + 4 * g4) = ha[rt];
-                } else {
-                    const bool ok = c0 + col < a.h2;
-                    const float bias = ok ? b2[c0 + col] : 0.0f;     // issued before the k-loop, needed after it
-                    f32x16 acc = {0};
-                    if (kn > 0)
-                        tile_gemm_packed<POLICY_SETS, TR>(acc, sh1 + (rh * 32 + col) * ld1 + 8 * (lane >> 5),
-                                            reinterpret_cast<const f32x4 *>(w2 + (size_t)chunk * nst * 512) + lane, kb >> 4, kn >> 4);
-                    if (!left || part == 0) acc = bias_mfma(acc, bias, lane);       // (packed W2 and the masked bias are zero beyond h2)
-                    if (!left) { store_tile_tr<true>(reg + col * kSt, acc, lane); l3 = true; }
-                    else store_tile_tr<false>(reg + col * kSt, acc, lane);           // this wave's partial tile (part 0: + bias)
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (l3) layer3_narrow(yn, reg, w3 + (size_t)c0 * a.nout, a.nout, min(32, a.h2 - c0), lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (tp.np) __syncthreads();                                 // the partial tiles are free again (slot 0 takes the layer-3 partials below)
-    } else {
     // Measured at the C5 shard: one leftover (13 chunks at h = 400) -5.5 %, -4.3 % at C3; two leftovers (10 chunks at h = 300)
     // as pairs -8.7 % (round 4; as two quarter-split trips, i.e. four barriers, +1.5 %); three leftovers (7 chunks at
     // h = 200) lose either way (three quarter-split trips +19 %, a pair trip + a quarter trip +4 %) and are dealt whole
@@ -763,7 +628,6 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
         __builtin_amdgcn_wave_barrier();
         if (left) __syncthreads();                               // the partial regions are free again
     }
-    }   // !TR
     PT(4);
     if (NARROW) {
 #pragma unroll
@@ -1074,6 +938,7 @@ template <int N, int I = 0, class F> __device__ __forceinline__ void for_each_sl
 struct MArgsX {
     int E, N, d_in, h1, h2, nc1, nc2;
     const float *x, *b1, *b2, *b3;
+    const float *wscale;           // f16x2: [N][3] power-of-two factors the packed weights were multiplied by, or NULL
     const char *ws;                // the per-(agent, wave) fragment streams
     int stages;                    // stages per stream (padded)
     FinishArgs fin;
@@ -1095,6 +960,7 @@ __device__ __forceinline__ unsigned upper_halves(unsigned odd, unsigned even)   
 //      dword of every part.
 struct SchemeBf16x3 {                                  // v = hi + mid + lo exactly (truncation), products >= 2^-16
     static constexpr int kParts = 3, kProducts = 6;
+    static constexpr bool kScaled = false;             // (an exact split: the weights' magnitude does not matter)
     __device__ static constexpr int w_part(int q) { constexpr int t[6] = {2, 1, 0, 1, 0, 0}; return t[q]; }   // lo.hi mid.mid hi.lo
     __device__ static constexpr int b_part(int q) { constexpr int t[6] = {0, 1, 2, 0, 1, 0}; return t[q]; }   // mid.hi hi.mid hi.hi
     __device__ static constexpr int last_use(int p) { constexpr int t[3] = {5, 3, 0}; return t[p]; }
@@ -1116,6 +982,9 @@ struct SchemeBf16x3 {                                  // v = hi + mid + lo exac
 };
 struct SchemeF16x2 {                                   // v = hi + lo to 2^-22 (float16 parts, subnormals honoured by the
     static constexpr int kParts = 2, kProducts = 3;    // matrix unit), products hi.hi, hi.lo, lo.hi; |v| < 65504
+    // the packed weights of a layer carry a power-of-two factor (DroneMlpBf16.wscale) that keeps their low parts out of the
+    // float16 subnormals; a layer's accumulators are multiplied by its inverse where they are split for the next layer
+    static constexpr bool kScaled = true;
     __device__ static constexpr int w_part(int q) { constexpr int t[3] = {1, 0, 0}; return t[q]; }            // lo.hi hi.lo hi.hi
     __device__ static constexpr int b_part(int q) { constexpr int t[3] = {0, 1, 0}; return t[q]; }
     __device__ static constexpr int last_use(int p) { constexpr int t[2] = {2, 0}; return t[p]; }
@@ -1144,10 +1013,13 @@ struct SplitJob {
     static constexpr int kStride = (kSlots - 2) / 4 > 0 ? (kSlots - 2) / 4 : 1;    // pairs behind slots 1, 1 + stride, ...
     const f32x16 &src;
     Parts<S::kParts> &dst;
-    __device__ __forceinline__ SplitJob(const f32x16 &s, Parts<S::kParts> &d) : src(s), dst(d) {}
+    const float mul;                                                               // S::kScaled: 1 / (the producing layer's weight factor)
+    __device__ __forceinline__ SplitJob(const f32x16 &s, Parts<S::kParts> &d, float m = 1.0f) : src(s), dst(d), mul(m) {}
     template <int Q> __device__ __forceinline__ void pair()                        // values 2 Q, 2 Q + 1 -> dword Q
     {
         unsigned d[S::kParts];
+        if constexpr (S::kScaled) S::template split_pair<true>(src[8 * HALF + 2 * Q] * mul, src[8 * HALF + 2 * Q + 1] * mul, d);
+        else
         S::template split_pair<true>(src[8 * HALF + 2 * Q], src[8 * HALF + 2 * Q + 1], d);
 #pragma unroll
         for (int p = 0; p < S::kParts; ++p) dst.p[p][Q] = d[p];
@@ -1210,6 +1082,16 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
     const int e0 = row_block * kRowsX;
     const int NC1 = a.nc1;
     const int nb = (a.nc1 + a.nc2) * 32;
+    // S::kScaled: the power-of-two factors of this agent's packed layers and their (exact) inverses
+    float ws1 = 1.0f, ws2 = 1.0f, wi1 = 1.0f, wi2 = 1.0f, wi3 = 1.0f;
+    if (S::kScaled && a.wscale != nullptr) {
+        const float *wsp = a.wscale + 3 * (size_t)agent;
+        const float ws3 = wsp[2];
+        ws1 = wsp[0]; ws2 = wsp[1];
+        wi1 = __uint_as_float(0x7f000000u - __float_as_uint(ws1));    // 2^-e from 2^e (normal powers of two: checked on the host side)
+        wi2 = __uint_as_float(0x7f000000u - __float_as_uint(ws2));
+        wi3 = __uint_as_float(0x7f000000u - __float_as_uint(ws3));
+    }
     if (kTrace && a.trace && lane == 0) {                          // shader clock and the 100 MHz clock at entry
         a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 0] = __builtin_amdgcn_s_memtime();
         a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1266,6 +1148,7 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
                                  : a.b3 + (size_t)agent * a.fin.nout + min(max(j3, 0), a.fin.nout - 1);
             const bool ok = in1 ? idx < a.h1 : in2 ? j2 < a.h2 : j3 < a.fin.nout;
             bv[it] = __uint_as_float(__float_as_uint(*p) & (ok ? 0xffffffffu : 0u));
+            if (S::kScaled) bv[it] *= in1 ? ws1 : in2 ? ws2 : 1.0f;    // b1, b2 start accumulators of SCALED products; b3 is added at the end
         }
 #pragma unroll
         for (int it = 0; it < kIt; ++it)
@@ -1354,20 +1237,20 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
             for (int t = 0; t < kTilesX; ++t) { a1[t] = bias_tile(sbias, lane); xB[t] = parts_from_lds<P>(sxb + t * kStageBytes + lane * 16); }
             stage(a1, xB, nojob);
 #pragma unroll
-            for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0, TILES> j(a1[t], hB0[t]); j.all(); }
+            for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0, TILES> j(a1[t], hB0[t], wi1); j.all(); }
         }
         for (int c1 = 0; c1 < NC1; ++c1) {
             // k-step 2 c1 of every chunk of mine; meanwhile the other half of a1 becomes hB1 (tile i in stage i)
 #pragma unroll
             for (int i = 0; i < kMaxChunks; ++i) {
                 if (i < nmine) {                                   // wave-uniform
-                    if (i < kTilesX) { SplitJobInStage<S, 1, TILES> j(a1[i], hB1[i]); stage(acc2[i], hB0, j); }
+                    if (i < kTilesX) { SplitJobInStage<S, 1, TILES> j(a1[i], hB1[i], wi1); stage(acc2[i], hB0, j); }
                     else stage(acc2[i], hB0, nojob);
                 }
             }
 #pragma unroll
             for (int t = 0; t < kTilesX; ++t)                     // tiles no stage of mine has dealt with (fewer chunks than tiles)
-                if (t >= nmine) { SplitJob<S, 1, TILES> j(a1[t], hB1[t]); j.all(); }
+                if (t >= nmine) { SplitJob<S, 1, TILES> j(a1[t], hB1[t], wi1); j.all(); }
             if (c1 + 1 < NC1) {                                    // layer 1 of the next chunk
                 Parts<P> xB[kTilesX];
                 a1[0] = bias_tile(sbias + (c1 + 1) * 32, lane);
@@ -1379,13 +1262,13 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
 #pragma unroll
             for (int i = 0; i < kMaxChunks; ++i) {
                 if (i < nmine) {
-                    if (i < kTilesX) { SplitJobInStage<S, 0, TILES> j(a1[i], hB0[i]); stage(acc2[i], hB1, j); }
+                    if (i < kTilesX) { SplitJobInStage<S, 0, TILES> j(a1[i], hB0[i], wi1); stage(acc2[i], hB1, j); }
                     else stage(acc2[i], hB1, nojob);
                 }
             }
 #pragma unroll
             for (int t = 0; t < kTilesX; ++t)
-                if (t >= nmine) { SplitJob<S, 0, TILES> j(a1[t], hB0[t]); j.all(); }
+                if (t >= nmine) { SplitJob<S, 0, TILES> j(a1[t], hB0[t], wi1); j.all(); }
         }
 
         // ---- layer 3 from the finished layer-2 accumulators, same stream
@@ -1394,10 +1277,10 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
             if (i < nmine) {
                 Parts<P> pB[kTilesX];
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0, TILES> j(acc2[i][t], pB[t]); j.all(); }
+                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 0, TILES> j(acc2[i][t], pB[t], wi2); j.all(); }
                 stage(y, pB, nojob);
 #pragma unroll
-                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 1, TILES> j(acc2[i][t], pB[t]); j.all(); }
+                for (int t = 0; t < kTilesX; ++t) { SplitJob<S, 1, TILES> j(acc2[i][t], pB[t], wi2); j.all(); }
                 stage(y, pB, nojob);
             }
         }
@@ -1427,9 +1310,16 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
             const int j = part + 4 * i;
             float v = 0.0f;
             if (j < a.fin.nout) {
-                v = sbias[nb + j];
+                if (S::kScaled) {                                  // the waves' partials carry layer 3's weight factor
+                    float pv = 0.0f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += spart[((size_t)w * kRowsX + row) * 33 + j];
+                    for (int w = 0; w < 4; ++w) pv += spart[((size_t)w * kRowsX + row) * 33 + j];
+                    v = fmaf(pv, wi3, sbias[nb + j]);
+                } else {
+                    v = sbias[nb + j];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) v += spart[((size_t)w * kRowsX + row) * 33 + j];
+                }
             }
             yv[i] = v;
         }
@@ -1596,6 +1486,7 @@ int mlp_forward_split(const char *what, const DroneMlpBf16 *m, const float *x, f
         return dronesim_fail(DRONESIM_EINVAL, msg);
     }
     a.x = x; a.b1 = m->b1; a.b2 = m->b2; a.b3 = m->b3;
+    a.wscale = S::kScaled ? m->wscale : nullptr;
     a.ws = reinterpret_cast<const char *>(m->w1p);
     a.trace = kTrace ? g_policy_trace : nullptr;
     a.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
@@ -1641,18 +1532,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     const size_t ld1 = packed ? (size_t)packed_row_stride(m->h1) : (size_t)m->h1 + 1;
     // (x rows: d_in + 1 floats; the h1 tile follows on a 16-byte boundary)
     const bool narrow = m->nout <= 16;                           // layer 3 on the 16-column matrix instruction
-    // transposed path: one set of per-wave tiles per leftover piece of a wave (tr_plan: at most two); the <= 16-feature tail
-    // chunk stays a piece of its own only while two workgroups still fit a CU's 160 KiB
-    const size_t base_lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * ld1);
-    const size_t tiles = sizeof(float) * (kThreadsF / 64) * 32 * (narrow ? kStN : kStW);
-    a.half_tail = 0;
-    size_t sets = 1;
-    if (packed && narrow) {
-        a.half_tail = 1;
-        if (tr_plan(m->h2, 1).np == 2 && 2 * (base_lds + 2 * tiles) > 160 * 1024) a.half_tail = 0;
-        sets = (size_t)(tr_plan(m->h2, a.half_tail).np > 1 ? 2 : 1);
-    }
-    const size_t lds = base_lds + sets * tiles;
+    const size_t lds = sizeof(float) * ((size_t)kRows * (m->d_in + 1) + (size_t)kRows * ld1 + (kThreadsF / 64) * 32 * (narrow ? kStN : kStW));
     if (lds > 160 * 1024) return dronesim_fail(DRONESIM_EUNSUPPORTED, "hidden layer too wide for the LDS tile");
     typedef void (*Kernel)(const float *, int, int, int, const MArgs);
     static const Kernel kernels[5] = {mlp3_kernel<false, false>, mlp3_kernel<false, true>, mlp3_kernel<true, false>, mlp3_kernel<true, true>,

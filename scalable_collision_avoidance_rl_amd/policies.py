@@ -148,6 +148,21 @@ def pack_split_streams(w1, w2, w3, stages, scheme="bf16x3"):
     return table[:, idx].contiguous()
 
 
+def f16_weight_scales(w1, w2, w3, target_exp=14):
+    """Power-of-two factors ``[N, 3]`` (float32) for the f16x2 weight image (include/dronesim.h: DroneMlpBf16.wscale):
+    layer l of agent i is multiplied by ``2^e`` with ``max |w| * 2^e`` in ``[2^(target_exp-1), 2^target_exp)`` before it
+    is split into float16 hi + lo, so that the low parts of all but the very smallest weights are NORMAL float16 numbers
+    (22 significant bits in all); unscaled, a weight of 0.05 has a subnormal low part and keeps an absolute 2^-25 only.
+    An all-zero layer gets 1."""
+    import torch
+    out = []
+    for w in (w1, w2, w3):
+        m = w.float().abs().flatten(1).amax(1)                              # [N]
+        e = torch.where(m > 0, target_exp - 1 - torch.floor(torch.log2(m.clamp_min(1e-37))), torch.zeros_like(m))
+        out.append(torch.exp2(e.clamp(-100, 100)))
+    return torch.stack(out, 1).contiguous()
+
+
 def pack_bf16x3_streams(w1, w2, w3, stages):
     return pack_split_streams(w1, w2, w3, stages, "bf16x3")
 
@@ -222,12 +237,16 @@ class BatchedMLP:
             if self.d_in > 16:
                 raise ValueError(f"the {precision} path supports d_in <= 16")
             stages = int(self._lib.dronesim_mlp_bf16x3_stages(self.h1, self.h2))
-            self._w1p = pack_split_streams(self.w1, self.w2, self.w3, stages, precision)
+            self._wscale = None
+            if precision == "f16x2":                               # power-of-two factors: the low parts stay normal float16
+                self._wscale = f16_weight_scales(self.w1, self.w2, self.w3)
+            self._w1p = self._split_image(stages)
             mb = _native.DroneMlpBf16()
             mb.N, mb.d_in, mb.h1, mb.h2, mb.nout = self.n_agents, self.d_in, self.h1, self.h2, self.nout
             mb.out_kind, mb.sample_kind, mb.reserved = self.out_kind, self.sample_kind, stages
             mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), None, None
             mb.b1, mb.b2, mb.b3 = self.b1.data_ptr(), self.b2.data_ptr(), self.b3.data_ptr()
+            mb.wscale = None if self._wscale is None else self._wscale.data_ptr()
             self._m = mb
         elif precision != "f32":
             raise ValueError("precision must be 'f32', 'f16x2', 'bf16x3' or 'bf16'")
@@ -251,9 +270,19 @@ class BatchedMLP:
             self._w3p.copy_(pack_bf16_fragments(self.w3, 2 * nc2, 1, k_order="accumulator"))
         else:
             stages = int(self._lib.dronesim_mlp_bf16x3_stages(self.h1, self.h2))
-            self._w1p.copy_(pack_split_streams(self.w1, self.w2, self.w3, stages, self.precision))
+            if self._wscale is not None:
+                self._wscale.copy_(f16_weight_scales(self.w1, self.w2, self.w3))
+            self._w1p.copy_(self._split_image(stages))
 
     load_weights = refresh_weights
+
+    def _split_image(self, stages):
+        """The packed weight streams of the split precisions; f16x2: of the weights times their power-of-two factors."""
+        if self._wscale is None:
+            return pack_split_streams(self.w1, self.w2, self.w3, stages, self.precision)
+        sc = self._wscale
+        return pack_split_streams(self.w1 * sc[:, 0, None, None], self.w2 * sc[:, 1, None, None], self.w3 * sc[:, 2, None, None],
+                                  stages, self.precision)
 
     # ------------------------------------------------------------------ constructors
     @classmethod

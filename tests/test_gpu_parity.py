@@ -344,13 +344,15 @@ def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch, prec):
     assert abs((eps ** 4).mean() - 3.0) < 0.08                                    # Gaussian, not just unit variance
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16x2"])
 def test_c5_gaussian_policy_stress_weights_hold_the_bar(torch, prec):
     """The precisions the C5 line is quoted with (bench.py `other_workloads.c5_gaussian_*`) hold the 1e-5 bar on the
     C5 shard's OWN observation (|z| up to ~243 on the 256 grid) at the builder's stress weights -- the case of
     tools/policy_accuracy.py / profiles/r2_policy_accuracy.log: full 400 x 4 output matrix at 2-3x the reference's
-    initialisation (utils.py:64-108 initialises U(+-1/sqrt(in))), where the two-part float16 split (f16x2) is at 2.0x
-    the bar and therefore NOT what C5 is quoted with."""
+    initialisation (utils.py:64-108 initialises U(+-1/sqrt(in))).  The two-part float16 split (f16x2) was at 2.0x the
+    bar here through round 4: the LOW parts of weights of this size are float16 subnormals (absolute 2^-25 instead of
+    2^-22 of the weight), an error the large activations of this case multiply; since round 5 its weight image carries
+    a power-of-two factor per (agent, layer) that keeps the low parts normal (DroneMlpBf16.wscale), and it holds the bar."""
     from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
     N, E, G = 256, 512, 256.0
     env = make_env(N, G, 2, 2, np.ones(N) * 2.5, E, seed=1)

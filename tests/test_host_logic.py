@@ -350,3 +350,30 @@ def test_bench_refuses_a_multi_gpu_run_it_cannot_start():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "refusing" in r.stderr
     assert not any(l.startswith("{") for l in r.stdout.splitlines())
+
+
+def test_f16x2_weight_factors_are_powers_of_two_that_keep_low_parts_normal():
+    """policies.f16_weight_scales (DroneMlpBf16.wscale, include/dronesim.h): per (agent, layer) a power of two that puts the
+    layer's largest weight into [2^13, 2^14) -- inside the float16 range, with the low part of every weight above
+    2^-3 x (largest / 2^14) a NORMAL float16; an all-zero layer gets 1.  And the ctypes mirror carries the field."""
+    import torch
+    from scalable_collision_avoidance_rl_amd.policies import f16_weight_scales, split2_f16
+    g = torch.Generator().manual_seed(3)
+    w1 = (torch.rand(3, 6, 40, generator=g) * 2 - 1) * 0.08
+    w2 = (torch.rand(3, 40, 40, generator=g) * 2 - 1) * torch.tensor([1e-6, 0.3, 900.0])[:, None, None]
+    w3 = torch.zeros(3, 40, 4)
+    sc = f16_weight_scales(w1, w2, w3)
+    assert sc.shape == (3, 3) and sc.dtype == torch.float32
+    m, e = torch.frexp(sc)
+    assert torch.all(m == 0.5) and torch.all(sc[:, 2] == 1.0)                 # exact powers of two; zero layer -> 1
+    for l, w in enumerate((w1, w2)):
+        top = (w.abs().flatten(1).amax(1) * sc[:, l])
+        assert torch.all(top >= 2.0 ** 13) and torch.all(top < 2.0 ** 14)
+    # what the factor buys: relative error of hi + lo over the weights of a layer of the reference's size
+    w = w1[0]
+    err = lambda x: float(((sum(split2_f16(x)).double() - x.double()).abs() / x.double().abs().clamp_min(1e-30))[x.abs() > 1e-3].max())
+    assert err(w) > 2.0 ** -19 and err(w * sc[0, 0]) <= 2.0 ** -21
+    header = open(_native.HEADER_PATH).read()
+    body = header[header.index("typedef struct DroneMlpBf16 {"):header.index("} DroneMlpBf16;")]
+    assert "const float *wscale;" in body and _native.DroneMlpBf16._fields_[-1][0] == "wscale"
+    assert C.sizeof(_native.DroneMlpBf16) == 8 * 4 + 7 * 8
