@@ -492,7 +492,7 @@ Geometry geometry(int N, int E)
 }
 
 // dynamic LDS of drone_kernel (must mirror the carve-up in the kernel)
-size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2)   // zc: columns of a staged z row (2, or 5 when those fit)
+size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2, bool rollout = false)   // zc: columns of a staged z row (2, or 5 when those fit)
 {
     const size_t nwaves = (size_t)g.threads / kWave;
     const size_t nconst = g.P > 0 ? nwaves : 1;
@@ -504,7 +504,7 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2)   // zc: col
     b += sizeof(unsigned) * nwaves * kWave * (size_t)(zc + 1) * (size_t)(k + 1);   // z (zc words) + Ni (1 word) per slot and lane
     // bucket filter tables: [2 axes][64 cells][words] per env slot, or kSym64's per-wave rows (whichever is larger)
     const size_t slots = g.P > 0 ? (size_t)g.epb : 1, words = g.P > 0 ? 1 : nwaves;
-    const size_t generic = (g.P > 0 && N < kBucketMinN) ? 0 : sizeof(unsigned long long) * slots * 2 * kCells * words;
+    const size_t generic = (g.P > 0 && N < kBucketMinN) ? 0 : sizeof(unsigned long long) * slots * 2 * ((g.P > 0 || rollout || g.threads > 256) ? kCells : kCellsBlock) * words;
     const size_t sym = g.P > 0 ? sizeof(ulonglong2) * nwaves * kBucketRows : 0;
     b += generic > sym ? generic : sym;
     return b;
@@ -602,7 +602,7 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     const bool epi_regions = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;   // the episode layer's regions: only when in use
     const size_t tail = epi_regions ? drone_lds_tail_bytes(g, p->N) : 0;
     // kSym64 has its own carve-up: one block per wave (positions, staging area, cell tables)
-    g.lds = g.geo == kSym64 ? (size_t)(g.threads / kWave) * sym_wave_bytes(p->k) : drone_lds_bytes(g, p->N, p->k);
+    g.lds = g.geo == kSym64 ? (size_t)(g.threads / kWave) * sym_wave_bytes(p->k) : drone_lds_bytes(g, p->N, p->k, 2, mode == kRollout);
     a.stage5 = 0; a.lds_vel = 0;
     if (p->c == 5 && g.geo == kSym64) {                 // per-wave blocks with 5-column rows, then the waves' velocities
         a.stage5 = 1;
@@ -612,7 +612,7 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
         // c = 5 rows: staged through LDS like the c = 2 ones, and the agents' velocities kept in LDS for the rows of the k
         // nearest, when the env's tile still fits (it does up to N = 1024 at k <= 5; the rows leave as 4-byte stores at a
         // 60-byte stride otherwise, as they all did through round 2)
-        const size_t lds5 = drone_lds_bytes(g, p->N, p->k, 5), vel = sizeof(float2) * (size_t)g.epb * (size_t)p->N;
+        const size_t lds5 = drone_lds_bytes(g, p->N, p->k, 5, mode == kRollout), vel = sizeof(float2) * (size_t)g.epb * (size_t)p->N;
         // (the velocity region is rounded up to 16 bytes: the episode layer reads its per-wave partial sums behind it as
         // ds_read_b128 -- 8 N bytes with odd N left `lds_tail` 8-byte aligned)
         const size_t vel16 = (vel + 15) & ~(size_t)15;
