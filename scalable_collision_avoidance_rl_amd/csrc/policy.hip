@@ -59,6 +59,7 @@ struct MArgs {
     const float *x, *w1, *b1, *w2, *b2, *w3, *b3;
     FinishArgs fin;
     long long *trace;                    // developer trace builds only (NULL otherwise)
+    unsigned rb_magic;                   // xcd_work_item: ceil(2^32 / row blocks), or 0
 };
 
 // LDS row stride (floats) of the h1 tile for the packed layer 2: whole 32-column chunks (the k padding is written as
@@ -74,12 +75,19 @@ __host__ __device__ __forceinline__ int packed_row_stride(int h1)
 // h = 300) do not fit one L2, a few agents' do.  So the work list is ordered agent-major and cut into 8
 // contiguous pieces, one per XCD: XCD x walks its own agents one after the other, the ~64 workgroups resident
 // on it at any time share one or two agents' weights, and every weight byte leaves HBM once per launch.
-__device__ __forceinline__ void xcd_work_item(int row_blocks, int &agent, int &row_block)
+// `magic` = ceil(2^32 / row_blocks) from the host when total x row_blocks < 2^32 (then umulhi(v, magic) = v / row_blocks
+// exactly for every v < total), else 0: a run-time integer division is ~25 instructions of this prologue, each of which
+// waits for an issue slot next to the other workgroup's matrix stream.
+__host__ inline unsigned div_magic(unsigned long long total, unsigned d)
+{
+    return (d > 1 && total * d < (1ull << 32)) ? (unsigned)(((1ull << 32) + d - 1) / d) : 0u;
+}
+__device__ __forceinline__ void xcd_work_item(int row_blocks, int &agent, int &row_block, unsigned magic = 0u)
 {
     const int total = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int q = total >> 3, r = total & 7;
     const int v = xcd * q + min(xcd, r) + slot;            // XCD x owns q + (x < r) items
-    agent = v / row_blocks;
+    agent = magic ? (int)__umulhi((unsigned)v, magic) : v / row_blocks;
     row_block = v - agent * row_blocks;
 }
 
@@ -111,12 +119,15 @@ __device__ __forceinline__ void finish_quad(const FinishArgs &a, float (&y)[kQ],
         float ssum = 0.0f;
 #pragma unroll
         for (int i = 0; i < kQ; ++i) {
-            if (4 * i < nout) { y[i] = part + 4 * i < nout ? expf(y[i] - m) : 0.0f; ssum += y[i]; }
+            // (v_exp_f32 = 2^x, 1 ulp: the library expf is ~15 instructions of range reduction for arguments that are <= 0
+            // here, and every vector instruction of this tail waits for an issue slot next to the other workgroup's
+            // matrix stream -- about one per 64 cycles, DESIGN_LOG round 5)
+            if (4 * i < nout) { y[i] = part + 4 * i < nout ? __builtin_amdgcn_exp2f((y[i] - m) * 1.4426950408889634f) : 0.0f; ssum += y[i]; }
             else y[i] = 0.0f;
         }
         ssum += quad_perm<kQuadXor1>(ssum);
         ssum += quad_perm<kQuadXor2>(ssum);
-        const float inv = 1.0f / ssum;
+        const float inv = __builtin_amdgcn_rcpf(ssum);             // ssum in [1, nout]: v_rcp_f32, 1 ulp
 #pragma unroll
         for (int i = 0; i < kQ; ++i) y[i] *= inv;
     } else if (a.out_kind == 2) {                            // tanh means, sigmoid variances (utils.py:74-77)
@@ -124,7 +135,11 @@ __device__ __forceinline__ void finish_quad(const FinishArgs &a, float (&y)[kQ],
 #pragma unroll
         for (int i = 0; i < kQ; ++i) {
             const int j = part + 4 * i;
-            if (j < nout) y[i] = j < half ? tanhf(y[i]) : 1.0f / (1.0f + expf(-y[i]));
+            if (j < nout) {                                      // tanh = 1 - 2 / (e^2y + 1), sigmoid = 1 / (1 + e^-y): absolute 1e-7
+                const float ex = __builtin_amdgcn_exp2f(y[i] * (j < half ? 2.8853900817779268f : -1.4426950408889634f));
+                const float rc = __builtin_amdgcn_rcpf(ex + 1.0f);
+                y[i] = j < half ? fmaf(-2.0f, rc, 1.0f) : rc;
+            }
         }
     }
     const size_t row = (size_t)e * a.N + agent;
@@ -158,9 +173,9 @@ __device__ __forceinline__ void finish_quad(const FinishArgs &a, float (&y)[kQ],
             const int pick = min(below, nout - 1);
             if (part == 0) {
                 if (a.act_idx) a.act_idx[row] = pick;
-                if (a.act) {
-                    const float ang = (float)pick / (float)nout * 6.283185307179586f;
-                    *reinterpret_cast<float2 *>(a.act + row * 2) = make_float2(cosf(ang), sinf(ang));
+                if (a.act) {                                    // v_cos_f32 / v_sin_f32 take REVOLUTIONS: cos(2 pi pick / nout) directly
+                    const float rev = (float)pick * __builtin_amdgcn_rcpf((float)nout);
+                    *reinterpret_cast<float2 *>(a.act + row * 2) = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
                 }
             }
         } else {                                             // Gaussian, Box-Muller (utils.py:110-117); nout = 4:
@@ -169,8 +184,9 @@ __device__ __forceinline__ void finish_quad(const FinishArgs &a, float (&y)[kQ],
                 const uint32_t r0 = part == 0 ? rnd[0] : rnd[2], r1 = part == 0 ? rnd[1] : rnd[3];
                 const float u1 = ((float)(r0 >> 8) + 1.0f) * (1.0f / 16777216.0f);            // (0, 1]
                 const float u2 = (float)(r1 >> 8) * (1.0f / 16777216.0f);
-                const float n01 = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
-                a.act[row * 2 + part] = fmaf(sqrtf(var), n01, y[0]);
+                // Box-Muller on the hardware's log2 / sqrt / cos(2 pi x): v_log_f32, v_sqrt_f32, v_cos_f32 (input in revolutions)
+                const float n01 = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+                a.act[row * 2 + part] = fmaf(__builtin_amdgcn_sqrtf(var), n01, y[0]);
             }
         }
     }
@@ -369,7 +385,7 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int agent, row_block;
-    xcd_work_item((a.E + kRows - 1) / kRows, agent, row_block);
+    xcd_work_item((a.E + kRows - 1) / kRows, agent, row_block, a.rb_magic);
     // (rotating which wave owns the chunks 0, 4, 8, ... -- one more chunk than the others at h = 400 -- with the row block,
     // so that the heavy waves of the two workgroups on a CU sit on different SIMDs, was measured in round 3: +-1 %)
     const int cw = wave & 3, rh = wave >> 2;
@@ -411,6 +427,10 @@ __global__ void __launch_bounds__(kThreadsF, 2) mlp3_kernel(const float *x, int 
     }
     }
     // ---- x tile -> LDS (rows beyond E are zero)
+    if (a.d_in <= 8) {                                       // eight lanes per row: no per-thread division
+        const int r = tid >> 3, c = tid & 7, e = e0 + r;
+        if (c < a.d_in) sx[r * ldx + c] = e < a.E ? a.x[((size_t)e * a.N + agent) * a.d_in + c] : 0.0f;
+    } else
     for (int idx = tid; idx < kRows * a.d_in; idx += kThreadsF) {
         const int r = idx / a.d_in, c = idx - r * a.d_in;
         const int e = e0 + r;
@@ -1546,6 +1566,7 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
         if (lrc) return lrc;
     }
     const dim3 grid(((E + kRows - 1) / kRows) * m->N);
+    a.rb_magic = div_magic(grid.x, (unsigned)((E + kRows - 1) / kRows));
     hipLaunchKernelGGL(kernel, grid, dim3(kThreadsF), lds, static_cast<hipStream_t>(stream), a.x, a.E, a.N, a.d_in, a);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
