@@ -2,8 +2,8 @@
 
 Host-side mirror of `/root/reference/drone_env.py:53-401` (class `drones`) for the
 step()/reset()/get_local_states() hot path.  Everything per-timestep runs in the
-hand-written HIP kernels of csrc/dronesim.hip through the C ABI of
-include/dronesim.h; this file only owns the caller-facing surface:
+hand-written HIP kernels of csrc/drone_kernel.hpp (step / observe / rollout) and
+csrc/dronesim.hip (reset, controllers, reductions) through the C ABI of include/dronesim.h; this file only owns the caller-facing surface:
 
 * construction-time constants (goal ring, safety distance, Delta clip) computed once
   on the host exactly as the reference does (drone_env.py:83-91, 115-153),
