@@ -794,6 +794,23 @@ def test_learner_reductions_and_controllers_shape_fuzz(torch):
                            atol=H.ATOL + 0.1 * 2e-7 / 1e-2 ** 2)
 
 
+@pytest.mark.parametrize("T,E,N", [(17, 4096, 64), (9, 2048, 256), (11, 65536, 4), (7, 4100, 64), (5, 1 << 14, 64)])
+def test_returns_scan_four_columns_per_thread_window(torch, T, E, N):
+    """dronesim_returns moves four adjacent columns per thread as 16-byte accesses when N % 4 == 0 and 262144 <= E N < 2^20
+    (csrc/dronesim.hip: what C3's stored rollout is) and one column per thread otherwise: both sides of both edges of the
+    window against the oracle's scan (SAC_agents.py:304-307), with episode ends, a ragged last workgroup (E = 4100) and a
+    wave whose four-column threads span 64 envs (N = 4: the per-thread done-flag path)."""
+    from oracle.oracle import mc_returns as o_ret
+    from scalable_collision_avoidance_rl_amd.rollout_buffer import mc_returns
+    rng = np.random.default_rng(T * 7 + N)
+    r = rng.normal(0, 3, (T, E, N)).astype(np.float32)
+    done = (rng.random((T, E)) < 0.1).astype(np.uint8)
+    for d in (done, None):
+        G = mc_returns(torch.tensor(r, device="cuda:0"), 0.93, None if d is None else torch.tensor(d, device="cuda:0"))
+        ref = o_ret(r, 0.93, d)
+        H.assert_close(host(G), ref, f"returns T={T} E={E} N={N} done={d is not None}", rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(ref).max())))
+
+
 # ------------------------------------------------------------------------------- batched policies (SURVEY 8f-1)
 class _L:      # minimal stand-in exposing .weight [out,in] / .bias like torch.nn.Linear
     def __init__(self, w_in_out, b):
