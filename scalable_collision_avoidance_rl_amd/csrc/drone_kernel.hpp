@@ -855,7 +855,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 vxi = u.x; vyi = u.y;                         // drone_env.py:238
             }
             spos_env[agent] = make_float2(xi, yi);
-            if (FAR && a.stage5) { f32x2 v; v.x = vxi; v.y = vyi; *(lds_f32x2 *)(svel_a + 8u * (unsigned)agent) = v; }
+            if (FAR && a.stage5) { f32x2 v; v.x = vxi; v.y = vyi; *(lds_f32x2 *)(uintptr_t)(svel_a + 8u * (unsigned)agent) = v; }
             if (!use_bucket && !SYM) {                        // relative partner windows (dup index agent + r);
                 spos_env[agent + N] = make_float2(xi, yi);    // kSym64 writes them only when its fallback runs
                 spos_env[stride + agent + 1] = make_float2(xi, yi);
@@ -1373,7 +1373,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     float lj = __builtin_nanf("");
                     if (have[kth]) {
                         if (a.stage5) {
-                            const f32x2 v = *(const lds_f32x2 *)(svel_a + 8u * j);    // (written next to the positions, same sync)
+                            const f32x2 v = *(const lds_f32x2 *)(uintptr_t)(svel_a + 8u * j);    // (written next to the positions, same sync)
                             vj = make_float2(v.x, v.y);
                         } else if (rand_act) {                                // counter-based stream: any lane can
                             uint32_t o[4];                                    // restate any agent's action
@@ -1441,10 +1441,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
 #pragma unroll
             for (int kth = 0; kth <= K; ++kth) {              // one base each (formed early), immediate offsets
                 f32x2 v; v.x = zrx[kth]; v.y = zry[kth];
-                *(lds_f32x2 *)(zrow_a + 8 * kth) = v;
+                *(lds_f32x2 *)(uintptr_t)(zrow_a + 8 * kth) = v;
             }
 #pragma unroll
-            for (int kth = 0; kth <= K; ++kth) *(lds_u32 *)(nrow_a + 4 * kth) = (unsigned)nbv[kth];
+            for (int kth = 0; kth <= K; ++kth) *(lds_u32 *)(uintptr_t)(nrow_a + 4 * kth) = (unsigned)nbv[kth];
         }
         TRACE_MARK(4);
         // the staged rows are written and copied out by the SAME wave: a wave-level fence orders them.  The workgroup
@@ -1478,9 +1478,9 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 constexpr int rz = (nz + 4 * kWave - 1) / (4 * kWave), rn = (nn + 4 * kWave - 1) / (4 * kWave);
                 u32x4 vz[rz], vn[rn];
 #pragma unroll
-                for (int r = 0; r < rz; ++r) vz[r] = *(const lds_u32x4 *)(copy_a + r * 16 * kWave);
+                for (int r = 0; r < rz; ++r) vz[r] = *(const lds_u32x4 *)(uintptr_t)(copy_a + r * 16 * kWave);
 #pragma unroll
-                for (int r = 0; r < rn; ++r) vn[r] = *(const lds_u32x4 *)(copy_a + 4 * nz + r * 16 * kWave);
+                for (int r = 0; r < rn; ++r) vn[r] = *(const lds_u32x4 *)(uintptr_t)(copy_a + 4 * nz + r * 16 * kWave);
 #pragma unroll
                 for (int r = 0; r < rz; ++r)
                     if ((r + 1) * 4 * kWave <= nz || (int)lane * 4 < nz - r * 4 * kWave)
