@@ -1629,7 +1629,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 const int c_shift = ca.samp_shift, c_div_y = ca.div_y;
                 const float c_pitch = ca.pitch;
                 // (the sampling tables sit behind the per-wave partial sums, see the LDS carve-up)
-                int2 *tbl = reinterpret_cast<int2 *>(reinterpret_cast<float *>(smem + ca.lds_tail) + 2 * ((nwaves + 1) & ~1)) + (size_t)slot * nt;
+                // (workgroup-per-env geometries, single-step launches: the table shares the cell tables' region -- dead since pass 1;
+                // sized on the host as max(cell tables, sampling table).  The fused rollouts keep their own: sharing measured +2 % there)
+                int2 *tbl = (BLOCKGEO && !is_rollout(MODE)) ? reinterpret_cast<int2 *>(sbt_all)
+                                     : reinterpret_cast<int2 *>(reinterpret_cast<float *>(smem + ca.lds_tail) + 2 * ((nwaves + 1) & ~1)) + (size_t)slot * nt;
                 const uint32_t gid_c = ca.gid_base + (uint32_t)env;
                 int node = -1;
                 uint32_t round = 0;

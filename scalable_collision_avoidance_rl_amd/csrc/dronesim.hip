@@ -492,7 +492,9 @@ Geometry geometry(int N, int E)
 }
 
 // dynamic LDS of drone_kernel (must mirror the carve-up in the kernel)
-size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2, bool rollout = false)   // zc: columns of a staged z row (2, or 5 when those fit)
+// zc: columns of a staged z row (2, or 5 when those fit); samp: bytes of the in-kernel reset's sampling table when it shares the
+// cell tables' region (workgroup-per-env geometries, see drone_lds_tail_bytes)
+size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2, bool rollout = false, size_t samp = 0)
 {
     const size_t nwaves = (size_t)g.threads / kWave;
     const size_t nconst = g.P > 0 ? nwaves : 1;
@@ -504,7 +506,8 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2, bool rollout
     b += sizeof(unsigned) * nwaves * kWave * (size_t)(zc + 1) * (size_t)(k + 1);   // z (zc words) + Ni (1 word) per slot and lane
     // bucket filter tables: [2 axes][64 cells][words] per env slot, or kSym64's per-wave rows (whichever is larger)
     const size_t slots = g.P > 0 ? (size_t)g.epb : 1, words = g.P > 0 ? 1 : nwaves;
-    const size_t generic = (g.P > 0 && N < kBucketMinN) ? 0 : sizeof(unsigned long long) * slots * 2 * ((g.P > 0 || rollout || g.threads > 256) ? kCells : kCellsBlock) * words;
+    size_t generic = (g.P > 0 && N < kBucketMinN) ? 0 : sizeof(unsigned long long) * slots * 2 * ((g.P > 0 || rollout || g.threads > 256) ? kCells : kCellsBlock) * words;
+    if (g.P == 0 && samp > generic) generic = samp;
     const size_t sym = g.P > 0 ? sizeof(ulonglong2) * nwaves * kBucketRows : 0;
     b += generic > sym ? generic : sym;
     return b;
@@ -519,10 +522,15 @@ int samp_table_entries(int N)
 }
 
 // bookkeeping regions behind the bucket tables: [nwaves rounded to even][2] floats + [epb][table] int2
-size_t drone_lds_tail_bytes(const Geometry &g, int N)
+// Workgroup-per-env geometries, single-step launches (round 5): the sampling table of the in-kernel reset lives in the CELL
+// TABLES' region -- a reset runs behind the step's last use of the tables -- so the tail holds the partial sums only: 25.8 ->
+// 21.7 KiB per workgroup at N = 256 with the episode layer, 7 instead of 6 workgroups per CU (256 x 4096 envs: 20.0 -> 19.5 us).
+// The fused rollouts keep the table in the tail (sharing measured +2 % there: profiles/r5_abtest_sampling_table_alias.log).
+size_t drone_samp_bytes(const Geometry &g, int N) { return sizeof(int2) * (size_t)g.epb * samp_table_entries(N); }
+size_t drone_lds_tail_bytes(const Geometry &g, int N, bool single_step)
 {
     const size_t nwaves = (size_t)g.threads / kWave;
-    return sizeof(float) * 2 * ((nwaves + 1) & ~(size_t)1) + sizeof(int2) * (size_t)g.epb * samp_table_entries(N);
+    return sizeof(float) * 2 * ((nwaves + 1) & ~(size_t)1) + ((g.P == 0 && single_step) ? 0 : drone_samp_bytes(g, N));
 }
 
 int check_params(const DroneParams *p, int E)
@@ -600,9 +608,11 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
         ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
         g.geo = kBlockU256;
     const bool epi_regions = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;   // the episode layer's regions: only when in use
-    const size_t tail = epi_regions ? drone_lds_tail_bytes(g, p->N) : 0;
+    const size_t tail = epi_regions ? drone_lds_tail_bytes(g, p->N, mode != kRollout) : 0;
     // kSym64 has its own carve-up: one block per wave (positions, staging area, cell tables)
-    g.lds = g.geo == kSym64 ? (size_t)(g.threads / kWave) * sym_wave_bytes(p->k) : drone_lds_bytes(g, p->N, p->k, 2, mode == kRollout);
+    const bool share = g.P == 0 && mode != kRollout;                                    // the sampling table shares the cell tables' region
+    const size_t samp = (share && a.auto_reset) ? drone_samp_bytes(g, p->N) : 0;
+    g.lds = g.geo == kSym64 ? (size_t)(g.threads / kWave) * sym_wave_bytes(p->k) : drone_lds_bytes(g, p->N, p->k, 2, mode == kRollout, samp);
     a.stage5 = 0; a.lds_vel = 0;
     if (p->c == 5 && g.geo == kSym64) {                 // per-wave blocks with 5-column rows, then the waves' velocities
         a.stage5 = 1;
@@ -612,7 +622,7 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
         // c = 5 rows: staged through LDS like the c = 2 ones, and the agents' velocities kept in LDS for the rows of the k
         // nearest, when the env's tile still fits (it does up to N = 1024 at k <= 5; the rows leave as 4-byte stores at a
         // 60-byte stride otherwise, as they all did through round 2)
-        const size_t lds5 = drone_lds_bytes(g, p->N, p->k, 5, mode == kRollout), vel = sizeof(float2) * (size_t)g.epb * (size_t)p->N;
+        const size_t lds5 = drone_lds_bytes(g, p->N, p->k, 5, mode == kRollout, samp), vel = sizeof(float2) * (size_t)g.epb * (size_t)p->N;
         // (the velocity region is rounded up to 16 bytes: the episode layer reads its per-wave partial sums behind it as
         // ds_read_b128 -- 8 N bytes with odd N left `lds_tail` 8-byte aligned)
         const size_t vel16 = (vel + 15) & ~(size_t)15;
