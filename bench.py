@@ -28,6 +28,9 @@ job split over the ranks.  --workload c2|c5 select the other single-GPU-sized co
 them (c2, the c5 shard, the c5 shard with the float32 Gaussian policy in the loop) after the graded region and
 appends them as `other_workloads`.
 
+The JSON line is kept under 8 KB (the driver keeps an 8 KB tail of stdout): numbers with 5-6 significant digits and short
+keys, no prose -- what every key means, and the workload behind every side line, is in DESIGN.md section 7.
+
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python bench.py --gpus 8 --steps 2000 --warmup 200        # starts its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -56,15 +59,15 @@ GRAPH_LAUNCHES = int(os.environ.get("BENCH_GRAPH_LAUNCHES", "4000"))   # launche
 
 WORKLOADS = {
     #        N    E/GPU  G      Delta  label
-    "c2": (5, 1024, 5.0, 1.0, "C2: n=5 x 1024 envs/GPU, Delta=1.0, G=5, random actions"),
-    "c3": (64, 4096, 28.0, 1.0, "C3: n=64 x 4096 envs/GPU, Delta=1.0, G=28, random actions"),
-    "c5": (256, 512, 256.0, 2.5, "C5-shard: n=256 x 512 envs/GPU, Delta=2.5, G=256, random actions"),
+    "c2": (5, 1024, 5.0, 1.0, "C2 n=5x1024"),
+    "c3": (64, 4096, 28.0, 1.0, "C3 n=64x4096"),
+    "c5": (256, 512, 256.0, 2.5, "C5-shard n=256x512"),
 }
 # side lines only (`other_workloads`): the shapes that carry the "boundary amortised" part of the roofline argument
 SIDE_WORKLOADS = {
-    "c3_8192": (64, 8192, 28.0, 1.0, "n=64 x 8192 envs on one GPU (2 x C3), Delta=1.0, G=28, random actions"),
-    "c4_one_gpu": (64, 32768, 28.0, 1.0, "C4 as ONE job on one GPU: n=64 x 32768 envs (BASELINE configs[3] on one rank), Delta=1.0, G=28, random actions"),
-    "c5_full": (256, 4096, 256.0, 2.5, "C5 as ONE job on one GPU: n=256 x 4096 envs (BASELINE configs[4]'s env axis on one rank), Delta=2.5, G=256, random actions"),
+    "c3_8192": (64, 8192, 28.0, 1.0, "n=64x8192"),
+    "c4_one_gpu": (64, 32768, 28.0, 1.0, "C4 n=64x32768 on one rank"),
+    "c5_full": (256, 4096, 256.0, 2.5, "C5 n=256x4096 on one rank"),
 }
 
 
@@ -84,17 +87,14 @@ def pmc_traffic(workload):
 
 def reference_record(workload):
     """The reference's OWN `drones.step()` timing at this shape (tools/time_reference.py, measured in the build
-    container where /root/reference exists; it cannot travel to the GPU box) -- attached beside the live figure
-    of the C port so that both CPU numbers stand next to the GPU one."""
+    container where /root/reference exists; it cannot travel to the GPU box: profiles/reference_cpu.json) -- attached
+    beside the live figure of the C port so that both CPU numbers stand next to the GPU one."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu.json")))
         sh = rec["shapes"][workload]
-        return {"kind": "reference", "source": "profiles/reference_cpu.json (tools/time_reference.py)",
-                "host": rec["host"]["cpu"], "where": rec["host"]["where"],
-                "one_core_agent_steps_per_s": sh["one_core"]["agent_steps_per_s"],
-                "one_core_ms_per_step": sh["one_core"]["ms_per_step"],
-                "whole_host_agent_steps_per_s": sh["whole_host"]["agent_steps_per_s"],
-                "whole_host_cores": sh["whole_host"]["cores"]}
+        return {"src": "profiles/reference_cpu.json", "core1": sh["one_core"]["agent_steps_per_s"],
+                "core1_ms_per_step": sh["one_core"]["ms_per_step"],
+                "host": sh["whole_host"]["agent_steps_per_s"], "host_cores": sh["whole_host"]["cores"]}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -122,8 +122,7 @@ def cpu_baseline(N, G, delta, budget_s=12.0):
         steps += 5
     el = time.perf_counter() - t0
     return {"value": N * E * steps / el, "unit": "agent-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/drone_oracle.c (float64 C restatement), {E} envs x {steps} steps, "
-                      f"{cores} OpenMP threads, {el:.1f} s"}
+            "sample": f"oracle/drone_oracle.c f64, {E} envs x {steps} steps, {cores} threads, {el:.1f} s"}
 
 
 def make_policy(torch, kind, precision, N, dev):
@@ -204,41 +203,31 @@ def side_workload(torch, dev, name, policy_kind=None, min_seconds=0.25, precisio
     steps = L * repeats
     kern_ms = step_kernel_ms(torch, env, pool, 5 * T_ep, reps=5)
     byt = algorithmic_bytes(N, E, True) + (36 * N * E if default_construction else 0)      # c = 5 rows: 60 B of z instead of 24
-    cfg_note = "BASELINE configs[4], one shard" if (name == "c5" and policy_kind == "gaussian") else f"the reference's {policy_kind} networks (utils.py:255-309 / 55-117) at this shape"
-    arith = {"f32": "exact float32 (v_mfma_f32_32x32x2_f32)", "bf16x3": "float32-accurate three-part bf16 split (6 x v_mfma_f32_32x32x16_bf16 per 16 k)",
-             "f16x2": "float32-accurate two-part float16 split (3 x v_mfma_f32_32x32x16_f16 per 16 k; |activations| < 65504)"}.get(precision, precision)
-    out = {"workload": label + (f" + {policy_kind} policy in the loop, {arith} ({cfg_note})" if policy else ""),
-           "value": N * E * steps / el, "unit": "agent-steps/s", "ms_per_step": el / steps * 1e3, "timed_steps": steps,
-           "timed_seconds": el, "step_kernel_ms": kern_ms,
-           "roofline": {"bound": "hbm", "achieved": byt / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": byt / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byt,
-                        "kernel": "drone_kernel<K=2,FAR=%d,step,episode layer>" % (1 if default_construction else 0)}}
-    if policy is not None:                             # the policy kernel alone (exact-f32 MFMA), same events-around-a-graph method
+    ms = el / steps * 1e3
+    out = {"v": N * E * steps / el, "ms_per_step": ms, "steps": steps, "step_kernel_ms": kern_ms,
+           "frac": byt / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "B": byt}
+    if policy is not None:
+        # the policy launch alone (events around a graph of 20 back-to-back calls, median of five replays) ...
         pg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(pg):
             for _ in range(20):
                 policy.sample_action(env.z, env=env)
         pg.replay(); torch.cuda.synchronize()
         ts = []
-        for _ in range(5):                             # median of five replays (one alone still carries the clock ramp:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)   # it came out ABOVE the
-            e0.record(); pg.replay(); e1.record(); torch.cuda.synchronize()                       # in-the-loop step time)
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); pg.replay(); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1) / 20)
-        pol_ms = float(np.median(ts))
+        alone_ms = float(np.median(ts))
+        # ... and IN THE LOOP: what the policy launch adds to a step of the timed loop = loop time per step minus the step
+        # launch's own time (the figure the roofline below is priced on; it cannot exceed ms_per_step)
+        pol_ms = ms - kern_ms
         flops = 2.0 * E * N * (policy.d_in * policy.h1 + policy.h1 * policy.h2 + policy.h2 * policy.nout)
-        out["policy_kernel_ms"] = pol_ms
-        if precision == "f32":
-            out["policy_roofline"] = {"bound": "mfma", "achieved": flops / (pol_ms * 1e-3) / 1e12, "peak": 157.3,
-                                      "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / 157.3,
-                                      "kernel": "mlp3_kernel (v_mfma_f32_32x32x2_f32, layer 3 on v_mfma_f32_16x16x4_f32; exact float32)"}
-        else:                                          # six bf16 (three f16) products per float32-equivalent product on the 2.5 PFLOP/s pipe
-            nprod = 6.0 if precision == "bf16x3" else 3.0
-            mf = nprod * flops
-            out["policy_roofline"] = {"bound": "mfma", "achieved": mf / (pol_ms * 1e-3) / 1e12, "peak": 2500.0,
-                                      "unit": "TFLOP/s", "frac": mf / (pol_ms * 1e-3) / 1e12 / 2500.0,
-                                      "float32_equivalent_tflops": flops / (pol_ms * 1e-3) / 1e12,
-                                      "kernel": "mlp3_split_kernel<%s> (16-bit matrix flops actually issued: %d per float32 product)"
-                                                % ("SchemeBf16x3" if precision == "bf16x3" else "SchemeF16x2", int(nprod))}
+        nprod = {"f32": 1.0, "bf16x3": 6.0, "f16x2": 3.0}.get(precision, 1.0)   # matrix products issued per float32 product
+        peak = 157.3 if precision == "f32" else 2500.0
+        out.update({"policy_kernel_ms": pol_ms, "policy_alone_ms": alone_ms, "pol_tf": nprod * flops / (pol_ms * 1e-3) / 1e12,
+                    "pol_peak": peak, "pol_frac": nprod * flops / (pol_ms * 1e-3) / 1e12 / peak,
+                    "f32_eq_tf": flops / (pol_ms * 1e-3) / 1e12})
     del graph, env, pool
     torch.cuda.empty_cache()
     return out
@@ -272,11 +261,8 @@ def aux_kernels(torch, dev):
     T, E, N = 200, 4096, 64
     out = {}
 
-    def line(what, us, byt, kernel, note):
-        gbs = byt / (us * 1e-6) / 1e9
-        return {"workload": what, "us_per_call": us, "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                                 "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": byt,
-                                                                 "kernel": kernel}, "note": note}
+    def line(what, us, byt, kernel, note):      # (what / kernel / note: documentation of the call sites)
+        return {"us": us, "frac": byt / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "B": byt}
     g = torch.Generator(device=dev).manual_seed(5)
     r = torch.randn(T, E, N, device=dev, generator=g)
     done = torch.zeros(T, E, dtype=torch.uint8, device=dev); done[-1] = 1
@@ -304,7 +290,7 @@ def aux_kernels(torch, dev):
     for kind, lines in (("proportional", "drone_env.py:652-679"), ("gradient", "drone_env.py:609-650")):
         us = graph_time_us(torch, lambda: env.control(kind), 40)
         out[f"control_{kind}"] = line(f"{kind}_control for all agents of C3 ({lines})", us, E * N * 16,
-                                      "control_kernel", "reads pos 8 B, writes act 8 B per agent: a 4 MB launch (launch-floor-bound)")
+                                      "control_kernel", "reads pos 8 B, writes act 8 B per agent: a 4 MB launch")
     del env
     torch.cuda.empty_cache()
     return out
@@ -333,8 +319,7 @@ def rccl_probe():
         for line in r.stdout.splitlines():
             if line.startswith("RCCL_US"):
                 _, us, ok = line.split()
-                return {"world_size": 1, "all_gather_into_tensor_8_doubles_us": float(us), "result_correct": ok == "True",
-                        "note": "RCCL collective of the exchange, timed back to back in a world of one (separate process)"}
+                return {"world": 1, "all_gather_8_doubles_us": float(us), "ok": ok == "True"}
     except (subprocess.SubprocessError, OSError, ValueError):
         pass
     return None
@@ -389,12 +374,56 @@ def device_span(workload):
         for line in r.stdout.splitlines():
             if line.startswith("SPAN_JSON "):
                 d = json.loads(line[10:])
-                d["how"] = ("tools/trace_span.py on libdronesim_span.so (-DDRONESIM_TRACE_SPAN): 64 traced step launches in one "
-                            "hipGraph, medians; 10 ns clock")
                 return d
     except (subprocess.SubprocessError, OSError, ValueError):
         pass
     return None
+
+
+def compact(o, sig=5):
+    """Numbers of the JSON line at `sig` significant digits (floats that are whole numbers print as integers)."""
+    if isinstance(o, dict):
+        return {k: compact(v, 7 if k in ("value", "timed_seconds", "v") else sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [compact(v, sig) for v in o]
+    if isinstance(o, (float, np.floating)):
+        f = float(o)
+        if f != f or f in (float("inf"), float("-inf")):
+            return None
+        if f == int(f) and abs(f) < 1e15:
+            return int(f)
+        return float(f"{f:.{sig}g}")
+    if isinstance(o, np.integer):
+        return int(o)
+    return o
+
+
+def c1_compat(torch, dev, episodes=3):
+    """BASELINE configs[0]'s shape (n = 5, ONE env, 200-step episodes) through the E = 1 drop-in face: the loop of
+    train_problem.py:82-107 -- list-of-ndarray actions in, the reference's 6-tuple of host objects out, env.reset() between
+    episodes -- in ms per step() call, next to the reference's own step() on one CPU core (profiles/reference_cpu.json).
+    Every call pays one host-to-device copy, one launch and one device-to-host copy + sync: a compatibility face, never `value`."""
+    from scalable_collision_avoidance_rl_amd import drones, max_time_steps
+    N = 5
+    env = drones(N, 0, [5.0, 5.0], "O", k_closest=2, deltas=np.ones(N), simplify_zstate=True, device=dev, seed=7)
+    rng = np.random.default_rng(0)
+    acts = [[rng.uniform(-1, 1, 2) for _ in range(N)] for _ in range(max_time_steps)]
+    for a in acts[:20]:
+        env.step(a)
+    steps, t_step = 0, 0.0
+    for _ in range(episodes):
+        env.reset()
+        for a in acts:
+            t0 = time.perf_counter()
+            _, _, _, _, finished, _ = env.step(a)
+            t_step += time.perf_counter() - t0
+            steps += 1
+            if finished:
+                break
+    ref = reference_record("c2")                       # same n = 5, G = 5 shape, E = 1: the reference's step() on one core
+    ms = t_step / steps * 1e3
+    return {"ms_per_step": ms, "steps": steps, "v": N / (ms * 1e-3), "ref_ms_per_step": None if ref is None else ref["core1_ms_per_step"],
+            "vs_ref": None if ref is None else ref["core1_ms_per_step"] / ms}
 
 
 def main():
@@ -557,6 +586,22 @@ def main():
         repeats, copies, L, slots = 1, 1, K, 1
         ring = torch.zeros(1, 8, dtype=torch.float64, device=dev)
 
+    # world > 1: the figure the N-rank value is to be compared with -- the SAME graph replayed by rank 0 ALONE (the other
+    # ranks wait at the barrier below), i.e. this workload on one GPU with nothing else running on the node.  Computed by
+    # the script so that no reader has to pair lines of different runs.  (Untimed for the N-rank figure: it precedes it.)
+    n1 = None
+    if world > 1 and graph is not None and args.scaling == "weak":     # (strong: a rank's shard is not the N = 1 job)
+        barrier()
+        if rank == 0:
+            r1 = max(1, int(np.ceil(0.6 * args.min_seconds / one)))
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(r1):
+                graph.replay(); launches += L
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            n1 = {"value": N * E * L * r1 / e1, "ms": e1 / (L * r1) * 1e3}
+        barrier()
+
     # the exchange's collective half: ONE all-gather per replay of the ring's slots (64 B per slot and rank), issued
     # async on RCCL's own stream behind the replay that filled them; the rollout's next replay is not held up
     exchanges = []
@@ -592,9 +637,14 @@ def main():
         own = env.episode_totals().cpu()
         recorded = float(own[3] + own[7])
         assert recorded == float(launches) * E, f"episode records hold {recorded} env-steps, {launches} launches x {E} envs issued"
-    launch_check = {"launches_issued_per_rank": launches, "envs_per_rank": E,
+    # ... and over all ranks: sum of launches x envs of every rank (rank 0 also issued the N = 1 comparison replays)
+    issued = torch.tensor([float(launches) * E], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(issued, op=dist.ReduceOp.SUM)
+    launch_check = {"launches_rank0": launches, "envs_per_rank": E,
+                    "env_steps_issued_all_ranks": float(issued.item()),
                     "env_steps_recorded_all_ranks": summary["env_steps"],
-                    "ok": (not layer) or summary["env_steps"] == float(launches) * E_global}
+                    "ok": (not layer) or summary["env_steps"] == float(issued.item())}
 
     # measured latency of the exchange's collective on this job's process group (world > 1), outside the timed region
     allgather_us = None
@@ -690,6 +740,7 @@ def main():
         bytes_launch = algorithmic_bytes(N, E, layer)
         achieved = bytes_launch / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.workload) if (e_gpu == WORKLOADS[args.workload][1] and E == e_gpu) else (None, None)
+        fr52 = lambda us: 52.0 * N * E / (us * 1e-6) / 1e9 / HBM_PEAK_GBS
         out = {
             "metric": "env agent-steps/sec (n_agents x n_envs x steps)",
             "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -698,12 +749,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "n_agents": N, "envs_per_gpu": E, "n_envs_total": E_global,
                        "grid": G, "delta": delta, "k_closest": 2, "simplify_zstate": True,
-                       "launch": ((f"hipGraph of the {K} requested steps" + (f", captured {copies}x over ({L} launches)" if copies > 1 else "") +
-                                   f", replayed {repeats}x in the timed region") if graph is not None else "eager"),
-                       "episode_layer": ("per-step statistic + in-kernel auto-reset (dronesim_step_ex)" if layer else
-                                         "plain dronesim_step + reset kernel every 200 steps"),
-                       "actions": "pre-generated U(-1,1)^2, resident in HBM" if policy is None else
-                                  f"batched per-agent {args.policy} policy (random-init, {args.policy_precision} MFMA) on the observation",
+                       "launch": (f"hipGraph {K}x{copies} launches, {repeats} replays" if graph is not None else "eager"),
+                       "episode_layer": bool(layer),
+                       "actions": "pool U(-1,1)^2 in HBM" if policy is None else f"{args.policy} policy {args.policy_precision}",
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
@@ -711,40 +759,29 @@ def main():
                          "frac_survey_bytes": algorithmic_bytes(N, E, False) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "survey_bytes_per_launch": algorithmic_bytes(N, E, False),
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "drone_kernel<K=2,FAR=0,step,%s>" % ("episode layer" if layer else "plain"), "kernel_ms": kern_ms,
+                         "kernel": "drone_kernel<K=2,FAR=0,step,%s>" % ("epi" if layer else "plain"), "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": bytes_launch},
-            "exchange": {"what": "per-episode log of train_problem.py:118-121: fixed-order reduction of the per-env episode "
-                                 "records (dronesim_episode_reduce, in the capture) + all-gather of the reduced 8-double vectors",
-                         "reduce_every_steps": T_ep if L >= T_ep else L,
+            # the path's only exchange (train_problem.py:118-121): in-capture fixed-order reductions + one all-gather per replay
+            "exchange": {"reduce_every_steps": T_ep if L >= T_ep else L,
                          "reductions_in_timed_region": reductions,
                          "collectives_in_timed_region": len(exchanges),
                          "doubles_per_collective_and_rank": int(ring.numel()),
-                         "collective": ("all_gather_into_tensor over %s, world_size %d, async on the collective's stream"
-                                        % ("RCCL (backend nccl)" if backend == "nccl" else backend, world)) if world > 1 else
-                                       "none: world_size 1, the reduced vectors are already everywhere (see rccl_probe)",
                          "real_collective_ran": bool(world > 1),
                          "backend": backend if world > 1 else None,
                          "rccl_ranks": (dist.get_world_size() if (world > 1 and backend == "nccl") else 0),
                          "collective_latency_us": allgather_us},
             "launch_check": launch_check,
             "episode_end_stats": summary,
-            "eager": {"value": N * E_global * eager_steps / eager_elapsed, "ms_per_step": eager_elapsed / eager_steps * 1e3,
-                      "steps": eager_steps,
-                      "note": f"max(K, {EAGER_MIN_STEPS}) steps launched one by one from Python, no hipGraph (host launch latency included)"},
+            "eager": {"ms_per_step": eager_elapsed / eager_steps * 1e3, "steps": eager_steps},
+            # dronesim_rollout_ex (episode layer) / dronesim_rollout (plain) / dronesim_rollout_random: us per step, 52 B per agent-step
             "fused_rollout": None if ro_us is None else {
-                "us_per_step_per_gpu": ro_us, "agent_steps_per_s_per_gpu": N * E / ro_us * 1e6,
-                "roofline_frac_52B": 52.0 * N * E / (ro_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "note": "dronesim_rollout_ex on the bench's env (episode records + in-kernel reset on): 200 steps per launch, "
-                        "52 B/agent-step (no per-step state write-back); four launches per timing bracket",
-                "plain_entry_point": None if rp_us is None else {
-                    "us_per_step_per_gpu": rp_us, "agent_steps_per_s_per_gpu": N * E / rp_us * 1e6,
-                    "roofline_frac_52B": 52.0 * N * E / (rp_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                    "note": "dronesim_rollout (no episode layer) on an env of the same shape"},
-                "random_actions_in_kernel": None if rr_us is None else {
-                    "us_per_step_per_gpu": rr_us, "agent_steps_per_s_per_gpu": N * E / rr_us * 1e6,
-                    "note": "dronesim_rollout_random: actions drawn in the kernel (no action pool, 44 B/agent-step), "
-                            "episode records + in-kernel reset on"}},
+                "epi_us": ro_us, "epi_frac52": fr52(ro_us),
+                "plain_us": rp_us, "plain_frac52": None if rp_us is None else fr52(rp_us),
+                "rand_us": rr_us},
         }
+        if n1 is not None:          # the N = 1 figure of the SAME workload / episode layer, timed on rank 0 alone ahead of the N-rank region
+            out["n1"] = {"value": n1["value"], "ms_per_step": n1["ms"], "ratio": value / n1["value"],
+                         "efficiency": value / n1["value"] / world}
         if per_rank is not None:
             out["per_rank"] = per_rank
         if not args.no_cpu_baseline and world == 1:
@@ -764,6 +801,7 @@ def main():
                                     ("default_construction", "c3", None, "f32"),
                                     ("c5_gaussian_f32", "c5", "gaussian", "f32"), ("c5_gaussian_bf16x3", "c5", "gaussian", "bf16x3"),
                                     ("c5_gaussian_f16x2", "c5", "gaussian", "f16x2"),
+                                    ("c5_full_gaussian_f16x2", "c5_full", "gaussian", "f16x2"),   # configs[4]'s whole env axis WITH its policy, one rank
                                     ("c3_softmax16_f32", "c3", "softmax16", "f32")):
                 try:
                     other[key] = side_workload(torch, dev, wl, pk, precision=pr, default_construction=(key == "default_construction"))
@@ -773,6 +811,10 @@ def main():
                 other["aux_kernels"] = aux_kernels(torch, dev)
             except Exception as ex:
                 other["aux_kernels"] = {"error": f"{type(ex).__name__}: {ex}"}
+            try:                                        # BASELINE configs[0] shape through the E = 1 drop-in face
+                other["c1_compat"] = c1_compat(torch, dev)
+            except Exception as ex:
+                other["c1_compat"] = {"error": f"{type(ex).__name__}: {ex}"}
             out["other_workloads"] = other
         if world == 1 and not args.no_other_workloads and args.workload in ("c2", "c3", "c5") and policy is None and layer and not args.envs_per_gpu:
             torch.cuda.empty_cache()
@@ -782,7 +824,12 @@ def main():
             out["roofline"]["device_clock"] = ds
         if world == 1 and not args.no_rccl_probe:
             out["exchange"]["rccl_probe"] = rccl_probe()
-        print(json.dumps(out))
+        line = json.dumps(compact(out), separators=(",", ":"))
+        if len(line) > 7900:                            # the driver keeps 8 KB of stdout: never let the head fall off
+            print(f"bench.py: JSON line is {len(line)} bytes (> 7900): dropping episode_end_stats / per-rank detail", file=sys.stderr)
+            out.pop("episode_end_stats", None)
+            line = json.dumps(compact(out), separators=(",", ":"))
+        print(line)
     if world > 1:
         dist.destroy_process_group()
 

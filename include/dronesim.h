@@ -40,8 +40,8 @@
 extern "C" {
 #endif
 
-#define DRONESIM_VERSION 500           /* 0.5.0: the float64 verification entry points moved to libdronesim_verify.so (dronesim_verify.h);
-                                          DroneMlpBf16.wscale */
+#define DRONESIM_VERSION 600           /* 0.6.0: dronesim_reset_observe (env.reset() as one launch); 0.5.0: the float64 verification entry
+                                          points moved to libdronesim_verify.so (dronesim_verify.h), DroneMlpBf16.wscale */
 #define DRONESIM_MAX_K 8               /* k_closest supported by the kernels */
 #define DRONESIM_MAX_AGENTS 1024       /* one workgroup holds one env */
 
@@ -232,6 +232,16 @@ int dronesim_rollout_random(const DroneParams *p, const DroneEpisodeCtl *ctl, fl
 int dronesim_reset_ex(const DroneParams *p, const DroneEpisodeCtl *ctl, const uint8_t *mask,
                       float *pos, float *vel, int32_t *t, int32_t *node_out, int E, void *stream);
 
+/* env.reset() as ONE launch (drone_env.py:98-102 -> init_agents :171-212 -> rewards :208): draws the lattice nodes exactly
+ * as dronesim_reset does (same Philox stream, same acceptance rule: node ids bit-identical), writes pos / vel = 0 /
+ * t = 0 / episode += 1, retires the episode records of the envs it resets when ctl->acc is set (as dronesim_reset_ex), and
+ * computes the first observation z / nbr_idx of the new state like dronesim_observe -- from registers and LDS, without a
+ * second launch or a round trip of the state through HBM.  ctl supplies div_x, div_y, pitch, seed, env_base, episode
+ * (required) and acc (optional); mask as in dronesim_reset; node_out ([E][N], may be NULL) records the nodes drawn.      */
+int dronesim_reset_observe(const DroneParams *p, const DroneEpisodeCtl *ctl, const uint8_t *mask,
+                           float *pos, float *vel, int32_t *t, int32_t *node_out,
+                           float *z, int32_t *nbr_idx, int E, void *stream);
+
 /* out[0..7] = sums over the E records of (done_return, done_true_return, done_collisions, done_len, episodes,
  * ep_return, ep_true_return, ep_len), float64, one launch, fixed summation order (bit-reproducible).          */
 #define DRONESIM_EPISODE_REDUCE_DOUBLES 8
@@ -242,7 +252,8 @@ int dronesim_episode_reduce(const DroneEpisodeAcc *acc, int E, double *out, void
  *        u = k_gain (xF - x), norm capped at u_max (reference: k_gain = 1, u_max = 1)
  *   kind DRONESIM_CONTROL_GRADIENT      gradient_control(state, env, u_max)   drone_env.py:609-650
  *        u = clip(-(2 (x - xF) - 0.1 sum_{j != i, d_ij <= dhat_i} (x_i - x_j) / (d_ij |x_i - x_j|)), +-u_max)
- * pos [E][N][2] in, act [E][N][2] out.                                             */
+ * pos [E][N][2] in, act [E][N][2] out.  Reads p->N, xF, xF_lo, d_hat, radius; with d_hat_max / radius_max set (> 0 / >= 0)
+ * the gradient controller of envs of >= 40 agents finds its partners through the step kernel's cell-mask far filter.  */
 #define DRONESIM_CONTROL_PROPORTIONAL 0
 #define DRONESIM_CONTROL_GRADIENT 1
 int dronesim_control(const DroneParams *p, int kind, const float *pos, float *act, float u_max,

@@ -28,7 +28,7 @@ MAX_AGENTS = 1024
 STATS_SCRATCH_DOUBLES = 769          # DRONESIM_STATS_SCRATCH_DOUBLES (include/dronesim.h)
 EPISODE_REDUCE_DOUBLES = 8           # DRONESIM_EPISODE_REDUCE_DOUBLES
 SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_episode_stats", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
-           "dronesim_step_ex", "dronesim_step_call", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
+           "dronesim_step_ex", "dronesim_step_call", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_reset_observe", "dronesim_episode_reduce",
            "dronesim_mlp_forward_bf16x3", "dronesim_mlp_forward_f16x2", "dronesim_mlp_bf16x3_stages",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
@@ -144,9 +144,10 @@ def lib():
     L.dronesim_rollout_ex.argtypes = [P, PC] + [vp] * 10 + [i32, i32, vp]
     L.dronesim_rollout_random.argtypes = [P, PC] + [vp] * 10 + [i32, i32, vp]
     L.dronesim_reset_ex.argtypes = [P, PC] + [vp] * 5 + [i32, vp]
+    L.dronesim_reset_observe.argtypes = [P, PC] + [vp] * 7 + [i32, vp]
     L.dronesim_episode_reduce.argtypes = [vp, i32, vp, vp]
     for name in ("dronesim_step", "dronesim_observe", "dronesim_rollout", "dronesim_reset", "dronesim_step_ex",
-                 "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_episode_reduce",
+                 "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_reset_observe", "dronesim_episode_reduce",
                  "dronesim_episode_stats", "dronesim_version"):
         getattr(L, name).restype = C.c_int
     L.dronesim_last_error.restype = C.c_char_p

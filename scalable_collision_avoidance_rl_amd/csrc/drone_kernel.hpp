@@ -117,6 +117,8 @@ struct KArgs {
     int *nbr_final;
     int lds_tail;                   // byte offset of the bookkeeping regions behind the bucket tables
     int samp_tbl, samp_shift;       // in-kernel reset: entries of the sampling table per env slot (2^k >= 2 N), 32 - k
+    int do_reset;                   // observe mode only (dronesim_reset_observe): draw the state instead of loading it
+    int *node_out;                  //   optional record of the lattice nodes drawn, [E][N]
 };
 
 // @phase h_nbr_list
@@ -563,20 +565,28 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     const float2 *pos_in = reinterpret_cast<const float2 *>(a.pos) + wga0;
     const float2 *vel_in = reinterpret_cast<const float2 *>(MODE == kObserve ? a.vel : a.act) + wga0;
     asm volatile("" : : "s"(pos_in), "s"(vel_in));
+    // dronesim_reset_observe (observe mode, launch-uniform flag): the state is DRAWN below -- env.reset() as one launch --
+    // instead of being loaded; none of this exists in the step / rollout instantiations
+    const bool fresh = MODE == kObserve && a.do_reset != 0;
     if (valid) {
         // read once per launch: streaming loads (the state and the actions do not displace anything in L2)
         // (measured: -0.1 us at C3; the workgroup-per-env shapes at BASELINE size -- C5 shard, 2 MB of state --
         // are 0.2 us faster with plain loads, and a run-time choice costs more than either)
-        float2 p;
-        if (BLOCKGEO) {
+        float2 p = make_float2(0.f, 0.f);
+        if (fresh) {
+        } else if (BLOCKGEO) {
             p = pos_in[lane];
         } else {
             const f32x2 pl = __builtin_nontemporal_load(reinterpret_cast<const f32x2 *>(pos_in) + lane);
             p = make_float2(pl.x, pl.y);
         }
         if (MODE == kObserve) {
-            const float2 v = vel_in[lane];
-            vxi = v.x; vyi = v.y;
+            if (!fresh) {
+                const float2 v = vel_in[lane];
+                vxi = v.x; vyi = v.y;
+            } else {
+                epi = (uint32_t)a.episode[env];               // resets this env has seen so far: the stream id of the draw
+            }
         } else {
             if (rand_act) {
                 // no action pool: the first action is drawn below, once t and the episode counter have arrived
@@ -811,6 +821,68 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     if (is_rollout(MODE) && (SYM || !rand_act))
         asm volatile("" : : "v"(xi), "v"(yi), "v"(u0.x), "v"(u0.y), "v"(xFx), "v"(xFy), "v"(xLx), "v"(xLy), "v"(dhat), "v"(delta_i),
                      "v"(li), "v"(tcur), "v"(epi), "v"(accw.x), "v"(accw.y), "v"(accw.z), "v"(accw.w));
+    if (MODE == kObserve && fresh) {
+        // @phase reset_draw
+        // ---- env.reset() in ONE launch (drone_env.py:98-102, 171-212): N distinct lattice nodes per env by the rule of
+        // reset_kernel / the in-kernel reset of the episode layer (an unsettled agent settles on its proposal iff no settled
+        // agent holds that node and no lower-index agent proposed it this round; open-addressing table in LDS, keys compared
+        // exactly: node ids bit-identical to oracle_reset), then the hot path below observes the new state straight from
+        // registers / LDS -- no second launch, no round trip of the state through HBM (round 6: C3 12.5 us as two launches)
+        const int nt = a.samp_tbl;
+        int2 *tbl = reinterpret_cast<int2 *>(reinterpret_cast<float *>(smem + a.lds_tail) + 2 * ((nwaves + 1) & ~1)) + (size_t)slot * nt;
+        const bool rs = valid;
+        int node = -1;
+        uint32_t round = 0;
+        bool more;
+        do {
+            if (rs)
+                for (int o = agent; o < nt; o += N) tbl[o] = make_int2(-1, 0x7fffffff);
+            group_sync<WL>();
+            int prop = node, h = 0;
+            if (rs) {
+                if (node < 0)
+                    prop = (int)__umulhi(philox4x32_10_word0((uint32_t)agent, round, gid, epi, a.key0, a.key1), a.lat_M);
+                h = (int)(((uint32_t)prop * 0x9E3779B1u) >> a.samp_shift);
+                for (;;) {                                                // linear probing, load factor <= 1/2
+                    const int old = atomicCAS(&tbl[h].x, -1, prop);
+                    if (old == -1 || old == prop) break;
+                    h = (h + 1) & (nt - 1);
+                }
+                atomicMin(&tbl[h].y, node >= 0 ? -1 : agent);
+            }
+            group_sync<WL>();
+            if (rs && node < 0 && tbl[h].y == agent) node = prop;
+            const bool left = rs && node < 0;
+            more = WL ? (__builtin_amdgcn_ballot_w64(left) != 0ull) : (__syncthreads_or(left ? 1 : 0) != 0);
+            if (WL) group_sync<true>();                   // this round's reads before the next round's clearing
+            ++round;
+        } while (more && round < (1u << 20));
+        if (rs) {
+            if (node >= 0) {                              // (an agent still unsettled after 2^20 rounds keeps the origin)
+                const int idx = node / a.div_y, jdx = node - idx * a.div_y;
+                xi = (float)idx * a.pitch; yi = (float)jdx * a.pitch;         // drone_env.py:196-205
+            }
+            vxi = 0.f; vyi = 0.f;                                             // :189
+            st_g2(o_pos + 2 * lane, xi, yi);
+            st_g2(o_vel + 2 * lane, 0.f, 0.f);
+            if (a.node_out) a.node_out[wga0 + lane] = node;
+            if (agent == 0) {
+                a.t[env] = 0;                                                 // :100
+                a.episode[env] = (int)(epi + 1u);        // (every wave of the env read the old value ahead of the first barrier)
+                if (a.acc != nullptr) {                                       // train_problem.py:118-121: log, then reset
+                    double *rec = a.acc + 8 * (size_t)env;
+                    int *reci = reinterpret_cast<int *>(rec);
+                    if (reci[5] > 0) {                                        // ep_len: an episode was in progress
+                        rec[4] += rec[0]; rec[5] += rec[1];
+                        reinterpret_cast<long long *>(rec)[6] += reci[4];
+                        reinterpret_cast<long long *>(rec)[7] += reci[5];
+                        reci[6] += 1;
+                        rec[0] = 0.0; rec[1] = 0.0; reci[4] = 0; reci[5] = 0;
+                    }
+                }
+            }
+        }
+    }
     float2 unext = make_float2(0.f, 0.f);                    // fused rollout: the next step's action, in flight
     // @phase integrate
     for (int step = 0; step < nsteps; ++step) {

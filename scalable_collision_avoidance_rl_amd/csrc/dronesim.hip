@@ -103,12 +103,35 @@ __global__ void __launch_bounds__(1024) reset_kernel(const RArgs a)
 
 // ---------------------------------------------------------------------------------------
 // Classical controllers (drone_env.py:609-679), same lane <-> agent geometry as drone_kernel.
+// gradient_control sums a repulsion term over the partners inside dhat_i + l_i + l_j (:641-644).  Envs of >= kBucketMinN
+// agents find them the way the step kernel's far filter does (round 6): every agent ORs its bit into the mask of its x
+// cell and of its y cell (64 hashed cells per axis, at least one reach wide), an agent's candidates are
+// (3 x masks) & (3 y masks), and only those get the exact test -- in ascending partner order, so the sum is the one the
+// all-partner loop forms (far partners never contributed a term): C3 12.8 -> see DESIGN.md section 7.  Smaller envs keep the loop.
 struct CArgs {
     int N, E, P, epb, kind;
     float u_max;
     const float *xF, *xF_lo, *d_hat, *radius, *pos;
     float *act;
+    int bucket, tab_off;            // cell-mask filter in use; byte offset of its tables in LDS
+    float inv_cell;                 // 1 / cell width
 };
+
+// one ordered pair of the repulsion sum (:639-644); `cand` = the conservative reach test of the far filter
+__device__ __forceinline__ void gradient_pair(float xi, float yi, float ri, float dhat, float2 pj, float rj, float &t2x, float &t2y)
+{
+    const float dx = xi - pj.x, dy = yi - pj.y;
+    const float d2 = fmaf(dy, dy, dx * dx);
+    const float reach = dhat + ri + rj;
+    if (d2 <= reach * reach * 1.000001f) {
+        const float nrm = sqrtf(d2);
+        const float dij = nrm - ri - rj;                                     // :641
+        if (dij <= dhat) {                                                   // :643
+            const float w = 1.0f / (dij * nrm);
+            t2x = fmaf(dx, w, t2x); t2y = fmaf(dy, w, t2y);                  // :644
+        }
+    }
+}
 
 template <bool WL>
 __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
@@ -131,9 +154,14 @@ __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
     }
     const size_t wga0 = (size_t)env0 * N + (WL ? 0 : wave * kWave);
     const bool valid = (int)lane < nval;
+    const bool gradient = a.kind == DRONESIM_CONTROL_GRADIENT;               // launch-uniform
+    const bool bucket = gradient && a.bucket != 0;
     float2 *spos = reinterpret_cast<float2 *>(smem);                         // [epb][N]
     float *srad = reinterpret_cast<float *>(spos + (size_t)a.epb * N);       // [WL ? nwaves : 1][N]
     float *srad_w = srad + (WL ? (size_t)wave * N : 0);
+    // cell tables (bucket): [axis][W words of 64 agents][64 cells]; one env per wave (WL: N >= kBucketMinN) or per workgroup
+    const int W = WL ? 1 : nwaves;
+    unsigned long long *tb = reinterpret_cast<unsigned long long *>(smem + a.tab_off) + (WL ? (size_t)wave * 2 * kCells : 0);
     float xi = 0.f, yi = 0.f, xFx = 0.f, xFy = 0.f, xLx = 0.f, xLy = 0.f, dhat = 1.f, ri = 0.f;
     if (valid) {
         const float2 p = (reinterpret_cast<const float2 *>(a.pos) + wga0)[lane];
@@ -142,42 +170,55 @@ __global__ void __launch_bounds__(1024) control_kernel(const CArgs a)
         dhat = a.d_hat[(unsigned)agent];
         ri = a.radius[(unsigned)agent];
         xi = p.x; yi = p.y; xFx = g.x; xFy = g.y;
-        spos[(size_t)slot * N + agent] = p;
+        if (gradient) spos[(size_t)slot * N + agent] = p;
     }
-    if (WL) { if ((int)lane < N) srad_w[lane] = a.radius[lane]; }
-    else for (int s = tid; s < N; s += blockDim.x) srad_w[s] = a.radius[s];
-    (void)nwaves;
-    group_sync<WL>();
-    if (!valid) return;
+    if (gradient) {
+        if (WL) { if ((int)lane < N) srad_w[lane] = a.radius[lane]; }
+        else for (int s = tid; s < N; s += blockDim.x) srad_w[s] = a.radius[s];
+        if (bucket) {
+            if (WL) { for (int o = lane; o < 2 * kCells; o += kWave) tb[o] = 0ull; }
+            else for (int o = tid; o < 2 * kCells * W; o += blockDim.x) tb[o] = 0ull;
+        }
+        group_sync<WL>();
+    }
     float ux, uy;
-    if (a.kind == DRONESIM_CONTROL_PROPORTIONAL) {
+    if (!gradient) {
         ux = (xFx - xi) + xLx; uy = (xFy - yi) + xLy;                        // :667-668, k_gain = 1
         const float nrm = sqrtf(fmaf(uy, uy, ux * ux));
         if (nrm > a.u_max) { ux = ux / nrm * a.u_max; uy = uy / nrm * a.u_max; }   // :670-673
     } else {
         const float2 *pe = spos + (size_t)slot * N;
         float t2x = 0.f, t2y = 0.f;
-        for (int j = 0; j < N; ++j) {
-            const float2 pj = pe[j];
-            const float rj = srad_w[j];
-            const float dx = xi - pj.x, dy = yi - pj.y;
-            const float d2 = fmaf(dy, dy, dx * dx);
-            const float reach = dhat + ri + rj;
-            const bool cand = j != agent && d2 <= reach * reach * 1.000001f;
-            if (__builtin_amdgcn_ballot_w64(cand)) {                         // wave-uniform skip of the far majority
-                const float nrm = sqrtf(d2);
-                const float dij = nrm - ri - rj;                             // :641
-                if (cand && dij <= dhat) {                                   // :643
-                    const float w = 1.0f / (dij * nrm);
-                    t2x = fmaf(dx, w, t2x); t2y = fmaf(dy, w, t2y);          // :644
+        if (bucket) {
+            const int cx = (int)__builtin_floorf(xi * a.inv_cell) & (kCells - 1), cy = (int)__builtin_floorf(yi * a.inv_cell) & (kCells - 1);
+            if (valid) {
+                atomicOr(&tb[(agent >> 6) * kCells + cx], 1ull << (agent & 63));
+                atomicOr(&tb[(W + (agent >> 6)) * kCells + cy], 1ull << (agent & 63));
+            }
+            group_sync<WL>();
+            if (valid) {
+                const int cxm = (cx - 1) & (kCells - 1), cxp = (cx + 1) & (kCells - 1);
+                const int cym = (cy - 1) & (kCells - 1), cyp = (cy + 1) & (kCells - 1);
+                for (int w = 0; w < W; ++w) {                                // ascending partner order, like the loop below
+                    const unsigned long long *tx = tb + w * kCells, *ty = tb + (W + w) * kCells;
+                    unsigned long long m = (tx[cxm] | tx[cx] | tx[cxp]) & (ty[cym] | ty[cy] | ty[cyp]);
+                    if (w == (agent >> 6)) m &= ~(1ull << (agent & 63));
+                    while (m) {
+                        const int j = 64 * w + __builtin_ctzll(m);
+                        m &= m - 1ull;
+                        gradient_pair(xi, yi, ri, dhat, pe[j], srad_w[j], t2x, t2y);
+                    }
                 }
             }
+        } else if (valid) {
+            for (int j = 0; j < N; ++j)
+                if (j != agent) gradient_pair(xi, yi, ri, dhat, pe[j], srad_w[j], t2x, t2y);
         }
         const float gx = 2.0f * ((xi - xFx) - xLx) - 0.1f * t2x, gy = 2.0f * ((yi - xFy) - xLy) - 0.1f * t2y;   // :633, :646
         ux = fminf(fmaxf(-gx, -a.u_max), a.u_max);                           // :647
         uy = fminf(fmaxf(-gy, -a.u_max), a.u_max);
     }
-    (reinterpret_cast<float2 *>(a.act) + wga0)[lane] = make_float2(ux, uy);
+    if (valid) (reinterpret_cast<float2 *>(a.act) + wga0)[lane] = make_float2(ux, uy);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -607,8 +648,9 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     if (mode == kRollout && g.geo == kBlock256 && p->N == 256 && !far && a.uniform &&
         ((reinterpret_cast<uintptr_t>(a.z) | reinterpret_cast<uintptr_t>(a.nbr_idx)) & 15u) == 0)
         g.geo = kBlockU256;
-    const bool epi_regions = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0;   // the episode layer's regions: only when in use
-    const size_t tail = epi_regions ? drone_lds_tail_bytes(g, p->N, mode != kRollout) : 0;
+    // the episode layer's regions: only when in use (dronesim_reset_observe: the sampling table of its draw, kept in the tail)
+    const bool epi_regions = a.acc != nullptr || a.auto_reset != 0 || a.rand_act != 0 || a.do_reset != 0;
+    const size_t tail = epi_regions ? drone_lds_tail_bytes(g, p->N, mode != kRollout && !a.do_reset) : 0;
     // kSym64 has its own carve-up: one block per wave (positions, staging area, cell tables)
     const bool share = g.P == 0 && mode != kRollout;                                    // the sampling table shares the cell tables' region
     const size_t samp = (share && a.auto_reset) ? drone_samp_bytes(g, p->N) : 0;
@@ -717,6 +759,28 @@ int dronesim_observe(const DroneParams *p, const float *pos, const float *vel,
     a.pos = const_cast<float *>(pos); a.vel = const_cast<float *>(vel);
     a.reward = reward; a.true_reward = true_reward; a.z = z; a.nbr_idx = nbr_idx; a.n_coll = n_coll;
     a.mask = mask; a.T = 1;
+    return launch(kObserve, p, a, E, stream);
+}
+
+int dronesim_reset_observe(const DroneParams *p, const DroneEpisodeCtl *ctl, const uint8_t *mask, float *pos, float *vel,
+                           int32_t *t, int32_t *node_out, float *z, int32_t *nbr_idx, int E, void *stream)
+{
+    int rc = check_params(p, E);
+    if (rc) return rc;
+    if (!ctl || !ctl->episode) return fail(DRONESIM_EINVAL, "dronesim_reset_observe: ctl with the lattice, seed / env_base and episode is required");
+    if (!pos || !vel || !t || !z || !nbr_idx) return fail(DRONESIM_EINVAL, "dronesim_reset_observe: required buffer is NULL");
+    if (ctl->div_x < 1 || ctl->div_y < 1) return fail(DRONESIM_EINVAL, "bad E / lattice size");
+    const uint64_t M = (uint64_t)ctl->div_x * (uint64_t)ctl->div_y;
+    if (M < (uint64_t)p->N) return fail(DRONESIM_EINVAL, "lattice has fewer nodes than agents (random.sample would raise)");
+    if (M > 0xFFFFFFFFull) return fail(DRONESIM_EUNSUPPORTED, "lattice larger than 2^32 nodes");
+    KArgs a{};
+    a.pos = pos; a.vel = vel; a.t = t; a.z = z; a.nbr_idx = nbr_idx; a.mask = mask; a.T = 1;
+    a.do_reset = 1; a.node_out = node_out;
+    a.acc = reinterpret_cast<double *>(ctl->acc);             // retire the episode in progress (as dronesim_reset_ex does)
+    a.episode = ctl->episode;
+    a.key0 = (uint32_t)ctl->seed; a.key1 = (uint32_t)(ctl->seed >> 32);
+    a.gid_base = (uint32_t)ctl->env_base;
+    a.lat_M = (uint32_t)M; a.div_y = ctl->div_y; a.pitch = ctl->pitch;
     return launch(kObserve, p, a, E, stream);
 }
 
@@ -841,7 +905,18 @@ int dronesim_control(const DroneParams *p, int kind, const float *pos, float *ac
     a.N = p->N; a.E = E; a.P = g.P; a.epb = g.epb; a.kind = kind; a.u_max = u_max;
     a.xF = p->xF; a.xF_lo = p->xF_lo; a.d_hat = p->d_hat; a.radius = p->radius; a.pos = pos; a.act = act;
     const size_t nw = (size_t)g.threads / kWave;
-    const size_t lds = sizeof(float2) * (size_t)g.epb * p->N + sizeof(float) * (g.P > 0 ? nw : 1) * p->N;
+    size_t lds = sizeof(float2) * (size_t)g.epb * p->N + sizeof(float) * (g.P > 0 ? nw : 1) * p->N;
+    // gradient: the cell-mask far filter for envs of >= kBucketMinN agents (one env per wave, or one per workgroup)
+    // (needs the bounds d_hat_max / radius_max of DroneParams: a caller that left them unset keeps the all-partner loop)
+    const float cell_w = (p->d_hat_max + 2.0f * p->radius_max) * 1.001f;
+    a.bucket = (kind == DRONESIM_CONTROL_GRADIENT && p->N >= kBucketMinN && g.P <= 1 && p->d_hat_max > 0.0f && p->radius_max >= 0.0f &&
+                cell_w > 0.0f && cell_w < 3.0e38f) ? 1 : 0;
+    if (a.bucket) {
+        lds = (lds + 7) & ~(size_t)7;
+        a.tab_off = (int)lds;
+        a.inv_cell = 1.0f / cell_w;
+        lds += sizeof(unsigned long long) * 2 * kCells * nw;                 // [wave | word][axis][cell]
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (g.P > 0) hipLaunchKernelGGL(control_kernel<true>, dim3(g.blocks), dim3(g.threads), lds, s, a);
     else hipLaunchKernelGGL(control_kernel<false>, dim3(g.blocks), dim3(g.threads), lds, s, a);

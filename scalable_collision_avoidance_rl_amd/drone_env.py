@@ -385,20 +385,15 @@ class drones:
         m = None
         if mask is not None:
             m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
-        dx, dy = lattice_divisions(self.grid)
         p = self._params()
+        # ONE launch (dronesim_reset_observe): the lattice draw of dronesim_reset[_ex] -- same stream, same nodes -- and the
+        # first observation of the new state (drone_env.py:208-210), with the episode records of the envs it resets
+        # retired when the env keeps them.  (Two launches through round 5: reset kernel, then observe.)
         with torch.cuda.device(self.device):
-            if self._use_ctl:                        # also retires the episode records of the envs it resets
-                rc = self._lib.dronesim_reset_ex(C.byref(p), C.byref(self._ctl()), None if m is None else m.data_ptr(),
-                                                 self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
-                                                 None, self.n_envs, self._stream())
-            else:
-                rc = self._lib.dronesim_reset(C.byref(p), dx, dy, float(LATTICE_PITCH), self.seed,
-                                              self.env_lo, None if m is None else m.data_ptr(),
-                                              self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(),
-                                              self.episode.data_ptr(), None, self.n_envs, self._stream())
-            self._native.check(rc, "dronesim_reset")
-            self._observe(m)
+            rc = self._lib.dronesim_reset_observe(C.byref(p), C.byref(self._ctl()), None if m is None else m.data_ptr(),
+                                                  self.pos.data_ptr(), self.vel.data_ptr(), self.t.data_ptr(), None,
+                                                  self.z.data_ptr(), self.nbr_idx.data_ptr(), self.n_envs, self._stream())
+            self._native.check(rc, "dronesim_reset_observe")
         if m is None:
             self.internal_t = 0
         if renew_obstacles:

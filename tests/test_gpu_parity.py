@@ -482,6 +482,64 @@ def test_reset_matches_oracle_bit_exact_and_shards(torch):
             assert torch.equal(part.z, full.z[part.env_lo:part.env_hi])
 
 
+@pytest.mark.parametrize("N,G,E,k,c,dflt", [(5, 5.0, 333, 2, 2, False), (5, 5.0, 40, 2, 5, True), (33, 20.0, 50, 3, 2, False),
+                                            (48, 24.0, 70, 2, 2, False), (64, 28.0, 515, 2, 2, False), (64, 28.0, 64, 1, 2, False),
+                                            (64, 28.0, 96, 2, 5, True), (64, 7.0, 130, 4, 2, False), (100, 40.0, 37, 2, 2, False),
+                                            (256, 256.0, 19, 2, 2, False), (256, 64.0, 9, 2, 5, True), (600, 120.0, 5, 5, 2, False)])
+def test_reset_as_one_launch_equals_reset_then_observe(torch, N, G, E, k, c, dflt):
+    """dronesim_reset_observe (env.reset() as ONE launch, round 6) against the two launches it replaces, on every geometry
+    (packed / one env per wave / workgroup per env, FAR and c = 5 rows, crowded lattices): node ids bit-identical to
+    dronesim_reset_ex's AND the oracle's restatement of the stream; pos / vel / t / episode counters / retired episode
+    records identical; z / nbr_idx bit-identical to dronesim_observe of that state; masked-out envs untouched."""
+    import ctypes as C
+    rng = np.random.default_rng(N * 7 + E)
+    env = make_env(N, G, k, c, None if dflt else np.ones(N), E, seed=91, track_episodes=True)
+    lib, p, ctl = env._lib, env._params(), env._ctl()
+    dev = "cuda:0"
+    acts = torch.rand(3, E, N, 2, device=dev) * 2 - 1
+    for a in acts:                                   # episodes in progress: records to retire, t > 0
+        env.step(a)
+    m_np = (rng.random(E) < 0.6).astype(np.uint8)
+    for mask in (None, torch.tensor(m_np, device=dev)):
+        st = env.get_state()
+        z_keep, nb_keep = env.z.clone(), env.nbr_idx.clone()
+        # (a) two launches on copies of the state
+        pos2, vel2, t2 = st["pos"].clone(), st["vel"].clone(), st["t"].clone()
+        epi2, acc2 = st["episode"].clone(), st["episode_acc"].clone()
+        node2 = torch.full((E, N), -1, dtype=torch.int32, device=dev)
+        ctl2 = env._make_ctl(); ctl2.episode = epi2.data_ptr(); ctl2.acc = acc2.data_ptr()
+        mp = None if mask is None else mask.data_ptr()
+        assert lib.dronesim_reset_ex(C.byref(p), C.byref(ctl2), mp, pos2.data_ptr(), vel2.data_ptr(), t2.data_ptr(),
+                                     node2.data_ptr(), E, None) == 0
+        z2, nb2 = z_keep.clone(), nb_keep.clone()
+        assert lib.dronesim_observe(C.byref(p), pos2.data_ptr(), vel2.data_ptr(), None, None, z2.data_ptr(), nb2.data_ptr(),
+                                    None, mp, E, None) == 0
+        # (b) one launch on the env's own buffers
+        node1 = torch.full((E, N), -1, dtype=torch.int32, device=dev)
+        epi_before = host(env.episode).copy()
+        assert lib.dronesim_reset_observe(C.byref(p), C.byref(ctl), mp, env.pos.data_ptr(), env.vel.data_ptr(), env.t.data_ptr(),
+                                          node1.data_ptr(), env.z.data_ptr(), env.nbr_idx.data_ptr(), E, None) == 0, lib.dronesim_last_error()
+        torch.cuda.synchronize()
+        tag = f"N={N} k={k} c={c} masked={mask is not None}"
+        assert torch.equal(node1, node2), tag
+        for x, y, what in ((env.pos, pos2, "pos"), (env.vel, vel2, "vel"), (env.t, t2, "t"), (env.episode, epi2, "episode"),
+                           (env.episode_acc, acc2, "records"), (env.nbr_idx, nb2, "nbr_idx")):
+            assert torch.equal(x, y), (tag, what)
+        assert torch.equal(env.z.view(torch.int32), z2.view(torch.int32)), tag          # bit-identical, NaN ghost rows included
+        # the oracle's restatement of the stream
+        orc = Oracle(N, [G, G], k, None if dflt else np.ones(N), c == 2)
+        _, _, _, rnode, repi = orc.reset(E, 91, episode=epi_before.copy(), mask=None if mask is None else m_np)
+        sel = np.ones(E, bool) if mask is None else m_np.astype(bool)
+        np.testing.assert_array_equal(host(node1)[sel], rnode[sel], err_msg=tag)
+        np.testing.assert_array_equal(host(env.episode), repi, err_msg=tag)
+        if mask is not None:                            # masked-out envs: state, counters and observation untouched
+            keep = torch.tensor(~sel, device=dev)
+            assert torch.equal(env.pos[keep], st["pos"][keep]) and torch.equal(env.t[keep], st["t"][keep])
+            assert torch.equal(env.z[keep].view(torch.int32), z_keep[keep].view(torch.int32)) and bool((node1[keep] == -1).all())
+        for a in acts[:2]:
+            env.step(a)
+
+
 def test_reset_shape_fuzz_against_oracle(torch):
     """Seeded random (N, lattice, E, seed, env_base, episode counters, mask) through dronesim_reset and dronesim_reset_ex
     (the in-LDS hash-table sampler): node ids bit-exact vs the oracle's restatement of the stream, from lattices that
@@ -684,6 +742,29 @@ def test_controllers_golden_and_oracle(torch):
     H.assert_close(host(env.control("gradient", 0.7))[safe], orc.gradient_control(p64, 0.7)[safe], "grad oracle",
                    atol=H.ATOL + 0.1 * 2e-7 / 1e-2 ** 2)
     H.assert_close(host(env.control("proportional")), orc.proportional_control(p64), "prop oracle")
+
+
+@pytest.mark.parametrize("N,G,E,lo,hi", [(40, 20.0, 64, 6.0, 13.0), (48, 24.0, 64, -3.0, 4.0), (64, 28.0, 256, 2.0, 12.0),
+                                         (100, 40.0, 32, 10.0, 20.0), (256, 64.0, 16, -20.0, 80.0), (256, 256.0, 16, 100.0, 114.0),
+                                         (600, 120.0, 4, 40.0, 62.0)])
+def test_gradient_control_cell_filter_matches_the_oracle(torch, N, G, E, lo, hi):
+    """gradient_control (drone_env.py:609-650) on the cell-mask far filter (envs of >= 40 agents, one env per wave or per
+    workgroup, ragged last words, coordinates below zero and spans of more than 64 cells -- hashed cells alias): the oracle's
+    all-partner sum, agent by agent, wherever every d_ij is >= 1e-2 from 0 and from dhat_i."""
+    rng = np.random.default_rng(1000 + N + E)
+    env = make_env(N, G, 2, 2, np.ones(N), E)
+    orc = Oracle(N, [G, G], 2, np.ones(N), True)
+    pos = (lo + rng.random((E, N, 2)) * (hi - lo)).astype(np.float32)
+    env.set_state(pos)
+    p64 = pos.astype(np.float64)
+    d = np.linalg.norm(p64[:, :, None] - p64[:, None], axis=-1) - 0.2
+    d[:, np.arange(N), np.arange(N)] = 1e9
+    near = (d <= orc.d_hat[None, :, None]).sum(-1)
+    safe = np.minimum(np.abs(d), np.abs(d - orc.d_hat[None, :, None])).min(axis=2) > 1e-2          # [E, N]
+    assert safe.mean() > 0.3 and near[safe].max() >= 1 and (near[safe] > 0).mean() > 0.05          # (the sum is exercised)
+    # (u_max far above every gradient: nothing is clipped, the repulsion sum itself is compared)
+    got, want = host(env.control("gradient", 1e4)), orc.gradient_control(p64, 1e4)
+    H.assert_close(got[safe], want[safe], f"grad N={N}", rtol=1e-5, atol=H.ATOL + 0.1 * 2e-7 / 1e-2 ** 2 + 4 * float(np.spacing(np.float32(max(abs(lo), abs(hi), G)))))
 
 
 def test_closed_loop_proportional_control_reaches_the_goal(torch):

@@ -64,7 +64,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == sorted(_native.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dronesim_version() == 500
+    assert lib.dronesim_version() == 600
     assert lib.dronesim_error_string(0) == b"ok"
     assert b"invalid" in lib.dronesim_error_string(_native.EINVAL)
 
