@@ -284,9 +284,10 @@ def aux_kernels(torch, dev):
                  batched=True)
     us = graph_time_us(torch, lambda: env.reset(renew_obstacles=False), 20)
     out["reset"] = line(f"env.reset() of all {E} envs of C3: lattice draw without replacement (reset_kernel) + first observation "
-                        "(drone_kernel<observe>) (drone_env.py:98-102, 171-212)", us, E * N * (16 + 16 + 36) + E * 12,
-                        "reset_kernel + drone_kernel<K=2,FAR=0,observe,plain>",
-                        "two launches: writes pos 8 + vel 8; reads them back 16, writes z 24 + nbr_idx 12 per agent; t / episode per env")
+                        "(drone_kernel<observe>) (drone_env.py:98-102, 171-212)", us, E * N * (16 + 36) + E * 12,
+                        "drone_kernel<K=2,FAR=0,observe,plain> with the in-kernel draw (dronesim_reset_observe)",
+                        "ONE launch since round 6: writes pos 8 + vel 8 + z 24 + nbr_idx 12 per agent; t / episode per env "
+                        "(the two launches of rounds 1-5 also read pos / vel back: 68 B per agent)")
     for kind, lines in (("proportional", "drone_env.py:652-679"), ("gradient", "drone_env.py:609-650")):
         us = graph_time_us(torch, lambda: env.control(kind), 40)
         out[f"control_{kind}"] = line(f"{kind}_control for all agents of C3 ({lines})", us, E * N * 16,

@@ -1,7 +1,7 @@
 // Internal helpers shared by the translation units of libdronesim.so (not part of the C ABI).
 #pragma once
 
-// The only build switches of the product source: developer trace builds (per-wave phase stamps; tools/trace_*.py),
+// The only build switches of the product source: developer trace builds (per-wave phase stamps; tools/trace_*.py) and one A/B build,
 //   make -C csrc -j8 EXTRA=-DDRONESIM_TRACE OUT=../../build/libdronesim_trace.so OBJDIR=../../build/obj_trace
 #if defined(DRONESIM_TRACE)
 constexpr bool kTrace = true;
@@ -20,11 +20,26 @@ constexpr bool kTraceFine = true;
 #else
 constexpr bool kTraceFine = false;
 #endif
+// -DDRONESIM_PAIR_PARALLEL_STEP: the single-step kernels of one-env-per-wave launches (kSym64 step / observe) ALSO go through the
+// pair-parallel near-pair phase that the fused rollouts use (drone_kernel.hpp: measured slower there; the A/B build of round 6)
+#if defined(DRONESIM_PAIR_PARALLEL_STEP)
+constexpr bool kPairParallelStep = true;
+#else
+constexpr bool kPairParallelStep = false;
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 // records the thread-local error string returned by dronesim_last_error() and returns `code`
 __attribute__((visibility("hidden"))) int dronesim_fail(int code, const char *msg);
+
+// 32 x 32 -> 64-bit product (multiplier: a wave-uniform constant)
+__device__ __forceinline__ uint64_t mul_wide_u32(uint32_t k, uint32_t x)
+{
+    uint64_t r;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(r) : "s"(k), "v"(x) : "vcc");
+    return r;
+}
 
 // Philox4x32-10 (Salmon et al., SC'11), all four output words
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -32,8 +47,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // (the 64-bit products as ONE v_mad_u64_u32 each, by name: from __umulhi + a 32-bit multiply -- or from a 64-bit
+        // multiply in the source -- hipcc issues two quarter-rate multiplies for most of them, 37 instead of 20 in the ten rounds)
+        const uint64_t p0 = mul_wide_u32(0xD2511F53u, c0), p1 = mul_wide_u32(0xCD9E8D57u, c2);
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -69,6 +69,14 @@ constexpr float kSkin = 0.4f;       // fused rollout: slack of the register-resi
 constexpr int kBucketMax = 10;      // candidates per agent beyond which the all-pairs scan is cheaper
 constexpr int kFarAllMaxN = 8;      // FAR variant: envs this small send every pair through pass 2 (no filter, no far tail)
 constexpr float kLn2 = 0.693147180559945309f;
+// Round 6: pair-parallel near-pair phase of the one-env-per-wave kernels (kSym64, not FAR).  The env's unordered listed
+// pairs (i < j) are compacted into lanes through the wave's LDS block, every pair is evaluated ONCE for both of its rows
+// at full lane utilisation, and each row owner folds its partners' results in ascending partner order (the order of the
+// per-lane walk: sums and neighbour lists are bit-identical).  In the product it serves the FUSED ROLLOUTS, whose pair list
+// survives from rebuild to rebuild (in-kernel actions -5 %, pool actions -0.3 ... -0.5 %); the single-step kernels measured
+// +1.4 ... +2.8 % with it -- the same 319 vector instructions per wave as the per-lane walk's 320, at 65 instead of 56 %
+// lane utilisation, behind a longer chain of LDS round trips (profiles/r6_abtest_pair_parallel.log, r6_sq_c3_pair_parallel_step.csv;
+// DESIGN.md section 3) -- and keep the walk.  kPairParallelStep (common.hpp: -DDRONESIM_PAIR_PARALLEL_STEP) builds them with it.
 
 // kRolloutPool / kRolloutRand: the fused rollout of the episode layer with its action source known at COMPILE time (pool
 // actions / actions drawn in the kernel) -- the one-env-per-wave and N = 256 geometries (every BASELINE shape's rollout):
@@ -341,6 +349,22 @@ __device__ __forceinline__ float2 wave_sum64_pair(float a, float b)
     const float t = wave_sum64_tree(a, b);
     return make_float2(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 31)),
                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t), 63)));
+}
+
+// inclusive prefix sum of one int per lane over the wave's 64 lanes: quads and rows by row_shr 1, 2, 3 / 4 / 8 (lanes a shift
+// would pull from outside their row of 16 read zero), rows to the wave by row_bcast 15 / 31 -- seven DPP adds
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_zero_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true); }
+__device__ __forceinline__ int wave_incl_scan64(int v)
+{
+    int t = v + dpp_or_zero_i<0x111, 0xf>(v);
+    t += dpp_or_zero_i<0x112, 0xf>(v);
+    t += dpp_or_zero_i<0x113, 0xf>(v);                       // lane i of a row: v[i-3] + ... + v[i]
+    t += dpp_or_zero_i<0x114, 0xf>(t);                       // ... v[i-7] + ... + v[i]
+    t += dpp_or_zero_i<0x118, 0xf>(t);                       // prefix inside the row of 16
+    t += dpp_or_zero_i<0x142, 0xa>(t);                       // rows 1, 3 += lane 15 of rows 0, 2
+    t += dpp_or_zero_i<0x143, 0xc>(t);                       // rows 2, 3 += lane 31
+    return t;
 }
 
 // sum over the n consecutive lanes of a segment (an env slot of a packed wave); valid in the segment's first lane
@@ -720,7 +744,17 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                 sconst[s] = uniform ? make_float2(a.delta_u, a.radius_u) : make_float2(a.delta[s], a.radius[s]);
     }
 
+    // pair-parallel phase (kPairParallel): its LDS regions.  The pair list (i | j << 8, i < j; 2 bytes per pair) takes the
+    // place of the x cell table, which is dead once the candidates have been read (in the fused rollout the list lives there
+    // until the next rebuild zeroes the tables); results (d, log term, pair: 16 bytes per pair slot) and the rows' inboxes (one
+    // 64-bit mask of pair slots per agent) use the staging area, which is not written before the epilogue.
+    constexpr bool PP = SYM && !FAR && (is_rollout(MODE) || kPairParallelStep);
+    const unsigned pp_pairs_a = lds_addr(smem) + (unsigned)(reinterpret_cast<const char *>(sbx) - smem);
+    const unsigned pp_res_a = lds_addr(smem) + (unsigned)(reinterpret_cast<const char *>(stage_z) - smem);
+    unsigned long long *const pp_in = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(stage_z) + 16 * kWave);
+    static_assert(!PP || 64 * 3 * (K + 1) * 4 >= 16 * kWave + 8 * kWave, "results + inboxes fit the staging area");
     if (SYM && !is_rollout(MODE)) { sbx[lane] = 0ull; sby[lane] = 0ull; }   // (the fused rollout zeroes them per rebuild)
+    if (PP && !is_rollout(MODE)) pp_in[lane] = 0ull;
     // Workgroup-per-env, single step: the cell tables are zeroed HERE and the barrier that orders the zeroing (and the
     // words above) against the other waves' atomics is taken in the shadow of the state loads -- an LDS-only barrier
     // (__syncthreads() carries a release fence, i.e. a vmcnt(0) wait for the loads in flight).  One barrier instead of
@@ -764,6 +798,11 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
 #pragma unroll
     for (int w = 0; w < (CACHED_B ? WMAX : 1); ++w) candw[w] = 0ull;
     float refx = __builtin_nanf(""), refy = refx;            // NaN = no list yet
+    // pair-parallel phase: this lane's segment of the pair list (its partners j > lane: slots pp_off .. pp_off + pp_cnt - 1)
+    // and, in the fused rollout, the number of listed pairs (-1: no pair list, the per-lane masks `cand` are walked instead)
+    int pp_off = 0, pp_cnt = 0, pp_T = -1;
+    unsigned pp_pr = 0u;                                     // fused rollout: this PAIR lane's pair, read back once per rebuild
+    const unsigned long long above = ~((2ull << lane) - 1ull);   // lanes > this lane
     // self entry: d_ii = min(-2 l_i, dhat_i), ratio 1 -> log 0, never a collision (:323-325); N_delta[i,i] uses Delta_i (:346)
     float dii = fminf(-li - li, dhat);
     int in_range0 = ((dii <= delta_i) ? 1 : 0) - 1;
@@ -866,6 +905,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             st_g2(o_pos + 2 * lane, xi, yi);
             st_g2(o_vel + 2 * lane, 0.f, 0.f);
             if (a.node_out) a.node_out[wga0 + lane] = node;
+            TRACE_MARK(1);                                // (trace builds: the draw is done)
             if (agent == 0) {
                 a.t[env] = 0;                                                 // :100
                 a.episode[env] = (int)(epi + 1u);        // (every wave of the env read the old value ahead of the first barrier)
@@ -948,7 +988,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             const bool mv = valid && !(fmaf(my, my, mx * mx) <= moved2);
             if (__builtin_amdgcn_ballot_w64(mv) != 0ull && lane == 0) sred[2] = 1;
         }
-        TRACE_COARSE(1);
+        if (!(MODE == kObserve && fresh)) TRACE_COARSE(1);
         if (!EARLY_TABLES) group_sync<WL>();                 // (EARLY_TABLES: taken ahead of the loads' return)
         TRACE_COARSE(2);
         // CACHED_B: workgroup-uniform (every thread reads the same word; agent 0 clears it behind the verdict barrier)
@@ -998,6 +1038,78 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             in_range += pt.inm ? 1 : 0;
             if (FAR) vis_inm += (dhat <= cj.x) ? 1 : 0;
             list.template insert<decltype(defer)::value>(pt.d, j, dii);      // :338
+        };
+
+        // @phase pair_parallel
+        // ---- pair-parallel phase, part 1: compaction.  `up` = this lane's partners j > lane (candidates, or listed partners in
+        // the fused rollout).  Lane i's pairs take the slots [off_i, off_i + cnt_i) of the list (exclusive prefix sum of the
+        // counts over the wave), in ascending j: the list is sorted by (i, j).  Returns the number of pairs; the list is only
+        // written when it fits the wave's 64 pair lanes (the caller falls back to the per-lane walk otherwise).
+        auto pp_compact = [&](unsigned long long up) __attribute__((always_inline)) -> int {
+            const int cnt = __builtin_popcountll(up);
+            const int incl = wave_incl_scan64(cnt);
+            const int T = __builtin_amdgcn_readlane(incl, 63);
+            pp_cnt = cnt; pp_off = incl - cnt;
+            if (T <= kWave) {
+                unsigned wa = pp_pairs_a + 2u * (unsigned)pp_off;
+                while (up) {
+                    const unsigned j = (unsigned)__builtin_ctzll(up);
+                    up &= up - 1ull;
+                    *(__attribute__((address_space(3))) unsigned short *)(uintptr_t)wa = (unsigned short)(lane | (j << 8));
+                    wa += 2u;
+                }
+            }
+            return T;
+        };
+        // ---- parts 2 and 3.  Pair pass: lane p < T holds pair p = (i, j), i < j, and evaluates it ONCE: with uniform
+        // (dhat, Delta, l) the terms of (i, j) and (j, i) are the same numbers (d^2 is formed from squares, the radii commute).
+        // A pair inside the early-out radius leaves (d, log term, pair) in its result slot and raises bit p in row j's inbox;
+        // row i finds its own pairs through the ballot of the verdicts and its segment of the list.  Fold: a row's partners in
+        // ascending index = the set bits of inbox | own segment in ascending slot order (pairs (j, i), j < i, sit in earlier
+        // segments, ordered by j; the row's own pairs follow, ordered by j > i) -- the additions and list insertions of the
+        // per-lane walk in the same order, without its sqrt / log / compares.
+        auto pair_phase = [&](int T, int off, int cnt) __attribute__((always_inline)) {
+            typedef __attribute__((address_space(3))) unsigned short lds_u16;
+            if (is_rollout(MODE)) pp_in[lane] = 0ull;         // (step / observe: zeroed ahead of the loads' return)
+            const unsigned pr = CACHED ? pp_pr : *(const lds_u16 *)(uintptr_t)(pp_pairs_a + 2u * lane);
+            const unsigned pi = pr & 63u, pj = (pr >> 8) & 63u;   // (lanes >= T read stale entries: in range, masked below)
+            const float2 a0 = spos_env[pi], a1 = spos_env[pj];
+            const float dx = a0.x - a1.x, dy = a0.y - a1.y;
+            const float d2 = fmaf(dy, dy, dx * dx);
+            const bool nr = (int)lane < T && d2 < thr;
+            const unsigned long long nb = __builtin_amdgcn_ballot_w64(nr);
+            if (nr) {
+                const PairTerms<float> pt = pair_terms<float>(d2, a.radius_u, a.radius_u, dhat, log2_dhat, a.delta_u);
+                u32x4 r; r.x = __float_as_uint(pt.d); r.y = __float_as_uint(pt.lg); r.z = pr; r.w = 0u;
+                *(lds_u32x4 *)(uintptr_t)(pp_res_a + 16u * lane) = r;
+                atomicOr(&pp_in[pj], 1ull << lane);
+            }
+            group_sync<true>();
+            const unsigned long long seg = ((1ull << cnt) - 1ull) << (off & 63);   // (cnt <= kBucketMax; off = 64 only with cnt = 0)
+            const unsigned long long mine = pp_in[lane] | (nb & seg);
+            auto fold = [&](auto defer) __attribute__((always_inline)) {
+                unsigned long long m = mine;
+                while (m) {
+                    const int p = __builtin_ctzll(m);
+                    m &= m - 1ull;
+                    const u32x4 r = *(const lds_u32x4 *)(uintptr_t)(pp_res_a + 16u * (unsigned)p);
+                    const float d = __uint_as_float(r.x), lg = __uint_as_float(r.y);
+                    const int j = (int)((p < off ? r.z : (r.z >> 8)) & 63u);          // the OTHER end of the pair
+                    const bool inm = d <= a.delta_u;                                  // :328
+                    s_all += lg;                                                      // :283
+                    s_msk += inm ? lg : 0.0f;                                         // :282
+                    ncoll += (d < 0.0f) ? 1 : 0;                                      // :284, :327
+                    in_range += inm ? 1 : 0;
+                    list.template insert<decltype(defer)::value>(d, j, dii);         // :338
+                }
+            };
+            fold(Defer{});
+            if (__builtin_expect(list_degenerate(list), 0)) {
+                list.init(dii, agent);
+                in_range = in_range0;
+                s_all = 0.f; s_msk = 0.f; ncoll = 0;
+                fold(NoDefer{});
+            }
         };
 
         // @phase filter_generic2
@@ -1183,6 +1295,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
             for (int r0 = 1; r0 <= rmax; r0 += 64) {
                 // ---- pass 1: far filter, 16 partners in flight.  Result: one bit per partner to revisit.
                 unsigned long long near = 0ull;
+                bool pp_now = false;                          // wave-uniform: this step's pairs go through the pair-parallel phase
                 const int left = rmax - r0 + 1;
                 if (FAR && N <= kFarAllMaxN) {
                     // a handful of agents: every partner goes through pass 2 (the filter and the far tail cost more than
@@ -1195,8 +1308,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                         const float mx = xi - refx, my = yi - refy;
                         rebuild = __builtin_amdgcn_ballot_w64(!(fmaf(my, my, mx * mx) <= moved2)) != 0ull;
                         near = cand;
+                        pp_now = PP && pp_T >= 0;
                     }
                     if (rebuild) {
+                    pp_now = false;
                     // @phase filter_sym_bucket
                     // (a) bucket filter: cells of width >= the list radius along x and along y; a partner can
                     //     only be inside the radius if it sits in this agent's cell or a neighbouring one on
@@ -1216,9 +1331,15 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                                               (sby[cy - 1] | sby[cy] | sby[cy + 1]) & ~self;
                     unsigned long long hits = 0ull;          // bit j: agent j is inside the list radius
                     if (__builtin_expect(__builtin_amdgcn_ballot_w64(__builtin_popcountll(pool) > kBucketMax) == 0ull, 1)) {
+                        // single step: the candidate pairs themselves are compacted, the pair pass does the exact test
+                        if (PP && !CACHED) {
+                            pp_T = pp_compact(pool & above);
+                            pp_now = pp_T <= kWave;            // (more than 64 candidate pairs: the per-lane walk below)
+                        }
                         // (b) exact test of the few candidates
                         // (requesting 2 or 4 candidates' positions per LDS round trip was measured: +0.04 / +0.08 us per launch --
                         // this part of a wave is issue-bound, the other three waves of the SIMD cover the round trips)
+                        if (!pp_now)
                         while (pool) {
                             const int j = __builtin_ctzll(pool);
                             pool &= pool - 1ull;
@@ -1226,7 +1347,16 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                             const float dx = xi - pj.x, dy = yi - pj.y;
                             if (fmaf(dy, dy, dx * dx) < thr_list) hits |= 1ull << j;
                         }
+                        // fused rollout: the LISTED pairs (inside reach + skin) are compacted once per rebuild; every step's
+                        // pair pass drops the listed-but-currently-far ones by its exact test
+                        if (PP && CACHED) {
+                            pp_T = pp_compact(hits & above);
+                            if (pp_T > kWave) pp_T = -1;
+                            pp_now = pp_T >= 0;
+                            if (pp_now) pp_pr = *(const __attribute__((address_space(3))) unsigned short *)(uintptr_t)(pp_pairs_a + 2u * lane);
+                        }
                     } else {
+                    if (PP && CACHED) pp_T = -1;              // (a crowded env's list stays in the per-lane masks)
                     // @phase filter_sym_crowded
                     // (c) crowded env: every unordered pair once -- lane i tests partners i+1..i+32 and the
                     //     verdict reaches the other end as a rotated ballot.  The doubled / shifted copies of
@@ -1304,7 +1434,10 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
                     // entry (coincident agents, a larger partner over a smaller agent's centre) starts over with the
                     // general insertion, out of line
                     const unsigned long long near0 = near;
-                    if (uni_args) {
+                    if (PP && pp_now) {
+                        pair_phase(pp_T, pp_off, pp_cnt);
+                        near = 0ull;
+                    } else if (uni_args) {
                         while (near) {
                             const int u = __builtin_ctzll(near);
                             near &= near - 1ull;

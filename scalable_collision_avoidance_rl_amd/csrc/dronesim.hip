@@ -682,7 +682,7 @@ int launch(int mode, const DroneParams *p, KArgs &a, int E, void *stream)
     if (g.lds > 160 * 1024) return fail(DRONESIM_EUNSUPPORTED, "n_agents x k_closest too large for the 160 KiB LDS tile");
     a.N = p->N; a.c = p->c; a.max_steps = p->max_steps; a.E = E;
     a.P = g.P; a.epb = g.epb;
-    a.trace = ((kTrace || kTraceSpan) && mode == kStep) ? g_trace : nullptr;
+    a.trace = ((kTrace || kTraceSpan) && (mode == kStep || (mode == kObserve && a.do_reset))) ? g_trace : nullptr;
     a.dt = p->dt; a.q = p->q; a.b = p->b; a.done_radius = p->done_radius;
     a.ghost_factor = p->ghost_factor; a.radius_max = p->radius_max;
     a.reach_max = p->d_hat_max + 2.0f * p->radius_max;

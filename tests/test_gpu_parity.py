@@ -754,7 +754,11 @@ def test_gradient_control_cell_filter_matches_the_oracle(torch, N, G, E, lo, hi)
     rng = np.random.default_rng(1000 + N + E)
     env = make_env(N, G, 2, 2, np.ones(N), E)
     orc = Oracle(N, [G, G], 2, np.ones(N), True)
-    pos = (lo + rng.random((E, N, 2)) * (hi - lo)).astype(np.float32)
+    if hi - lo > 50:        # clusters in the corners of a span of more than 64 cells: dense inside, and the corners' cells alias
+        corner = rng.integers(0, 2, (E, N, 2))
+        pos = (np.where(corner == 1, hi - 10.0, lo) + rng.random((E, N, 2)) * 10.0).astype(np.float32)
+    else:
+        pos = (lo + rng.random((E, N, 2)) * (hi - lo)).astype(np.float32)
     env.set_state(pos)
     p64 = pos.astype(np.float64)
     d = np.linalg.norm(p64[:, :, None] - p64[:, None], axis=-1) - 0.2

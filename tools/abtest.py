@@ -6,6 +6,7 @@
     cases: comma list of  c3 (plain step) | c3e (step, episode layer + auto-reset: the graded kernel) | c3r (fused rollout)
            | c3rr (fused rollout, actions drawn in the kernel, episode layer) | c3re (fused rollout, pool actions, episode layer) | c5 | c5e | c5r | c2 | NxE:G:delta[e|r]
            | c3f / c5f / NxE:G:deltaf (the reference's DEFAULT construction: deltas=None, simplify_zstate=False -> FAR variant)
+           | c3x / c5x / NxE:G:deltax (env.reset() of all envs, us per call)
 
 Every (round, library) runs in its own process (the library is chosen at import time through DRONESIM_LIB)."""
 import json
@@ -27,7 +28,7 @@ def one(cases):
     for case in cases:
         mode = "plain"
         spec = case
-        for suffix, m in (("rr", "rollout_random"), ("re", "rollout_epi"), ("r", "rollout"), ("e", "epi"), ("f", "far")):
+        for suffix, m in (("rr", "rollout_random"), ("re", "rollout_epi"), ("r", "rollout"), ("e", "epi"), ("f", "far"), ("x", "reset")):
             if spec.endswith(suffix) and (spec[:-len(suffix)] in PRESETS or ":" in spec):
                 spec, mode = spec[:-len(suffix)], m
                 break
@@ -44,7 +45,19 @@ def one(cases):
         g = torch.Generator(device="cuda").manual_seed(0)
         T = 200
         ts = []
-        if mode in ("plain", "epi", "far"):
+        if mode == "reset":                               # env.reset() of all envs (c3x): us per call, 20 calls per graph
+            env.reset(renew_obstacles=False); torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for s in range(20):
+                    env.reset(renew_obstacles=False)
+            graph.replay(); torch.cuda.synchronize()
+            for _ in range(12):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); graph.replay(); b.record(); torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) / 20 * 1e3)
+            del graph
+        elif mode in ("plain", "epi", "far"):
             pool = torch.rand(T, E, N, 2, device="cuda", generator=g) * 2 - 1
             for s in range(10):
                 env.step(pool[s])
