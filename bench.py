@@ -359,6 +359,34 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def write_ceiling():
+    """What the chip sustains for the step kernel's dominant traffic -- a pure WRITE stream in the kernel's own shape (16 B per lane,
+    non-temporal) -- measured on THIS box by tools/stream_bw (tools/micro/stream_bw.hip, built by __graft_entry__.build()): sustained
+    GB/s of one launch over 2 GiB, and us per launch of 200 dependent launches writing 15.7 MB each (= what one C3 step launch writes:
+    the floor of any one-launch-per-step kernel with this output volume).  60 of the path's 76 B per agent-step are WRITTEN; HBM3E on
+    this part sustains ~4.3 TB/s of writes against ~7.1 TB/s of reads, so the 8 TB/s spec is not reachable for this mix.  None when the tool is not built."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "stream_bw")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        out = {}
+        for line in r.stdout.splitlines():
+            w = line.split()
+            if line.startswith("write one launch"):
+                out["write_GBps"] = float(w[w.index("->") + 1])
+            elif line.startswith("write 200 dependent"):
+                out["write_15p7MB_launch_us"] = float(w[w.index("us") - 1])
+            elif line.startswith("read  one launch"):
+                out["read_GBps"] = float(w[w.index("->") + 1])
+            elif line.startswith("copy  one launch"):
+                out["copy_GBps"] = float(w[w.index("->") + 1])
+        return out or None
+    except (subprocess.SubprocessError, OSError, ValueError):
+        return None
+
+
 def device_span(workload):
     """The step launches as the DEVICE sees them: first wave in -> last wave out (`span_us`) and last wave out -> the next
     launch's first wave (`boundary_us`) inside a hipGraph replay, from the waves' own entry / exit times on the chip-wide
@@ -823,6 +851,12 @@ def main():
             if ds is not None:                           # bytes moved inside the launch's own execution window
                 ds["frac_inside_span"] = bytes_launch / (ds["span_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             out["roofline"]["device_clock"] = ds
+            wc = write_ceiling()
+            if wc is not None and "write_GBps" in wc:    # bytes WRITTEN per launch (60 B per agent-step + per-env words) against the measured write rate
+                written = 60 * N * E + (9 + (32 if layer else 0)) * E
+                wc["written_bytes_per_launch"] = written
+                wc["frac"] = written / (kern_ms * 1e-3) / 1e9 / wc["write_GBps"]
+            out["roofline"]["write_ceiling"] = wc
         if world == 1 and not args.no_rccl_probe:
             out["exchange"]["rccl_probe"] = rccl_probe()
         line = json.dumps(compact(out), separators=(",", ":"))

@@ -873,27 +873,43 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
         int node = -1;
         uint32_t round = 0;
         bool more;
+        // The table is cleared ONCE and kept from round to round: a winner turns its entry into a blocker (owner -1), so at the top
+        // of every round the table holds exactly the settled agents' nodes -- what reset_kernel rebuilds by re-entering all of them
+        // after a clear -- and a later round costs the unsettled lanes' own probes only.  (The launch ends with its slowest wave: one
+        // env in eight needs a second round at C3, one in two thousand a third, and with the full re-entry each cost the wave as
+        // much as the first: trace of round 6, profiles/r6_trace_reset.log.)
+        if (rs)
+            for (int o = agent; o < nt; o += N) tbl[o] = make_int2(-1, 0x7fffffff);
+        group_sync<WL>();
         do {
-            if (rs)
-                for (int o = agent; o < nt; o += N) tbl[o] = make_int2(-1, 0x7fffffff);
-            group_sync<WL>();
-            int prop = node, h = 0;
-            if (rs) {
-                if (node < 0)
-                    prop = (int)__umulhi(philox4x32_10_word0((uint32_t)agent, round, gid, epi, a.key0, a.key1), a.lat_M);
+            const bool open = rs && node < 0;                 // unsettled: proposes this round
+            int prop = -1, h = 0, old = -1;
+            if (open) {
+                // (the key made opaque HERE: as a loop invariant its ten-round schedule -- 18 scalar registers -- is hoisted out
+                // of the sampling loop and pushes the kernel's pinned output bases into v_writelane spills around it)
+                uint32_t rk0 = a.key0, rk1 = a.key1;
+                asm volatile("" : "+s"(rk0), "+s"(rk1));
+                prop = (int)__umulhi(philox4x32_10_word0((uint32_t)agent, round, gid, epi, rk0, rk1), a.lat_M);
                 h = (int)(((uint32_t)prop * 0x9E3779B1u) >> a.samp_shift);
                 for (;;) {                                                // linear probing, load factor <= 1/2
-                    const int old = atomicCAS(&tbl[h].x, -1, prop);
+                    old = atomicCAS(&tbl[h].x, -1, prop);
                     if (old == -1 || old == prop) break;
                     h = (h + 1) & (nt - 1);
                 }
-                atomicMin(&tbl[h].y, node >= 0 ? -1 : agent);
             }
+            // wave-local geometries, first round: when no lane of the wave met its own node in the table, all proposals of the
+            // wave's envs are distinct and nothing is settled yet -- everybody wins, without the ownership exchange
+            if (WL && round == 0 && __builtin_amdgcn_ballot_w64(open && old == prop) == 0ull) {
+                if (open) node = prop;
+                more = false;
+                break;
+            }
+            if (open) atomicMin(&tbl[h].y, agent);            // owner = the lowest proposer (a blocker's -1 stays)
             group_sync<WL>();
-            if (rs && node < 0 && tbl[h].y == agent) node = prop;
+            if (open && tbl[h].y == agent) { node = prop; tbl[h].y = -1; }   // settled: the entry blocks the rounds to come
             const bool left = rs && node < 0;
             more = WL ? (__builtin_amdgcn_ballot_w64(left) != 0ull) : (__syncthreads_or(left ? 1 : 0) != 0);
-            if (WL) group_sync<true>();                   // this round's reads before the next round's clearing
+            if (WL) group_sync<true>();                       // this round's reads before the next round's atomics
             ++round;
         } while (more && round < (1u << 20));
         if (rs) {

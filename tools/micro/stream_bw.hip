@@ -77,6 +77,5 @@ int main()
         printf("%s 200 dependent launches x 15.7 MB : %8.3f us per launch -> %7.1f GB/s\n", names[kind], ts[3] * 1e3, mb / (ts[3] * 1e3) * 1e3);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
-    // (c) the env kernels' mixes in ONE sustained launch: per 16-byte element read r of every (r + w) elements
     return 0;
 }
