@@ -362,7 +362,7 @@ def spawn_ranks(n):
 def write_ceiling():
     """What the chip sustains for the step kernel's dominant traffic -- a pure WRITE stream in the kernel's own shape (16 B per lane,
     non-temporal) -- measured on THIS box by tools/stream_bw (tools/micro/stream_bw.hip, built by __graft_entry__.build()): sustained
-    GB/s of one launch over 2 GiB, and us per launch of 200 dependent launches writing 15.7 MB each (= what one C3 step launch writes:
+    GB/s of one launch over 2 GiB, and us per launch of 4000 dependent launches (one hipGraph) writing 15.7 MB each (= what one C3 step launch writes:
     the floor of any one-launch-per-step kernel with this output volume).  60 of the path's 76 B per agent-step are WRITTEN; HBM3E on
     this part sustains ~4.3 TB/s of writes against ~7.1 TB/s of reads, so the 8 TB/s spec is not reachable for this mix.  None when the tool is not built."""
     import subprocess
@@ -376,7 +376,7 @@ def write_ceiling():
             w = line.split()
             if line.startswith("write one launch"):
                 out["write_GBps"] = float(w[w.index("->") + 1])
-            elif line.startswith("write 200 dependent"):
+            elif line.startswith("write 4000 dependent"):
                 out["write_15p7MB_launch_us"] = float(w[w.index("us") - 1])
             elif line.startswith("read  one launch"):
                 out["read_GBps"] = float(w[w.index("->") + 1])

@@ -3,7 +3,8 @@
 // (60 of 76 B per agent-step written; 44 of 52 in the fused rollout) can be priced against what the chip sustains for such a mix,
 // not only against the 8 TB/s spec.
 //   hipcc -O3 --offload-arch=gfx950 -o tools/stream_bw tools/micro/stream_bw.hip && tools/stream_bw
-// Two regimes per kind: ONE launch over `big` bytes (2 GiB: sustained) and a hipGraph of 200 dependent launches over `small` bytes each
+// Two regimes per kind: ONE launch over `big` bytes (2 GiB: sustained) and a hipGraph of 4000 dependent launches (the benchmark's replay
+// length: a replay costs 0.1-0.3 ms of idle time whatever it holds, 0.5-1.5 us per launch of a 200-launch graph) over `small` bytes each
 // (15.7 MB = what one C3 step launch writes), rotating through a 1.9 GB buffer so that no launch rewrites lines still dirty in cache.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -55,8 +56,8 @@ int main()
         const double gb = (kind == 2 ? 2.0 : 1.0) * big / 1e9;
         printf("%s one launch over 2 GiB            : %8.3f ms  -> %7.1f GB/s%s\n", names[kind], ts[3], gb / (ts[3] * 1e-3),
                kind == 2 ? "  (read + written)" : "");
-        // (b) graph of 200 dependent launches, 15.7 MB each, one element per thread (the step kernel's grid shape: 4096 waves)
-        const int L = 200;
+        // (b) graph of 4000 dependent launches, 15.7 MB each, one element per thread (the step kernel's grid shape: 4096 waves)
+        const int L = 4000;
         const size_t n = small / 16, slots = (big - small) / small;
         hipGraph_t g; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
@@ -68,13 +69,13 @@ int main()
         CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
         CK(hipGraphLaunch(ge, st)); CK(hipStreamSynchronize(st));
         ts.clear();
-        for (int rep = 0; rep < 7; ++rep) {
+        for (int rep = 0; rep < 5; ++rep) {
             CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(ge, st)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms / L);
         }
         std::sort(ts.begin(), ts.end());
         const double mb = (kind == 2 ? 2.0 : 1.0) * small / 1e6;
-        printf("%s 200 dependent launches x 15.7 MB : %8.3f us per launch -> %7.1f GB/s\n", names[kind], ts[3] * 1e3, mb / (ts[3] * 1e3) * 1e3);
+        printf("%s 4000 dependent launches x 15.7 MB: %8.3f us per launch -> %7.1f GB/s\n", names[kind], ts[2] * 1e3, mb / (ts[2] * 1e3) * 1e3);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
     return 0;

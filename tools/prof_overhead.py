@@ -11,8 +11,10 @@ written per agent of a 64 x 4096 batch; 3.9-4.0 us per launch by HIP events), in
     rocprofv3 --kernel-trace --output-format csv -d DIR -- python tools/prof_overhead.py run > prof.log
     python tools/prof_overhead.py combine plain.log DIR prof.log <period.json of the profiled bench command> [bench.json] > profiles/r6_c3_period.json
 
-`combine` reports the stream kernel's begin->begin period under the profiler next to its HIP-event time without it -- the
-difference is the profiler's per-dispatch cost on this box -- and the step kernel's period with that cost taken off."""
+`combine` reports the stream kernel's begin->begin period under the profiler next to its HIP-event time without it.  Finding (round 6):
+the profiler's cost is not an additive term -- the 3.3-us kernel reads 5.1 us per launch in the trace: the kernel trace puts a FLOOR of
+about 5.1 us under the dispatch period of a replay, and the step kernel's own trace period (5.2 us) sits just above that floor, within 1.5 %
+of the unprofiled benchmark's 5.13 us per step."""
 import ctypes as C
 import json
 import os
@@ -81,31 +83,42 @@ def combine(plain_log, prof_dir, prof_log, period_json, bench_json=None):
     plain, under = calib_of(plain_log), calib_of(prof_log)
     per = trace_period(prof_dir, "probe_stream")
     step = json.load(open(period_json))
-    ev0 = plain["hip_event_us_per_launch"]["median"]
-    overhead = per["median"] - ev0
-    raw = step["period_begin_to_begin"]["median"]
     out = dict(step)
     out["profiler_overhead_calibration"] = {
         "kernel_of_known_duration": "probe_stream (tools/calib_copy.hip): 1024 x 256 threads, 16 B read + 56 B written per agent of 64 x 4096, "
                                     f"{plain['launches_per_replay']} dependent launches per hipGraph replay",
         "hip_events_no_profiler_us": plain["hip_event_us_per_launch"],
         "hip_events_under_rocprofv3_us": under["hip_event_us_per_launch"],
-        "trace_period_under_rocprofv3_us": per,
-        "per_dispatch_overhead_us": overhead,
-        "how": "trace period of the stream kernel under rocprofv3 --kernel-trace minus its HIP-event time per launch without the profiler, "
-               "same box, same call"}
-    out["period_corrected_us"] = raw - overhead
-    byt = step.get("algorithmic_bytes_per_launch")
-    if byt:
-        out["period_corrected_frac_of_8TBps"] = byt / ((raw - overhead) * 1e-6) / 1e9 / 8000.0
+        "trace_period_under_rocprofv3_us": per}
+    restate(out, bench_json)
+    print(json.dumps(out, indent=1))
+
+
+def restate(out, bench_json=None):
+    """The reading of the calibration.  The profiler's cost is NOT an additive per-dispatch term: a kernel that takes 3.3 us per launch by
+    HIP events shows a 5.1 us begin->begin period in the trace -- rocprofv3's kernel trace puts a FLOOR under the dispatch period of a
+    hipGraph replay (its completion-signal handling serialises dispatches), and any kernel shorter than the floor reads as the floor."""
+    cal = out["profiler_overhead_calibration"]
+    ev0 = cal["hip_events_no_profiler_us"]["median"]
+    floor = cal["trace_period_under_rocprofv3_us"]["median"]
+    raw = out["period_begin_to_begin"]["median"]
+    cal["profiler_dispatch_floor_us"] = floor
+    cal["floor_over_true_duration"] = floor / ev0
+    cal["reading"] = (f"a {ev0:.2f}-us kernel reads {floor:.2f} us per launch in the trace: the kernel trace puts a floor of ~{floor:.1f} us under the "
+                      "dispatch period of a replay on this box (not an additive cost), so the trace cannot resolve a step launch shorter than "
+                      "that; the step kernel's own period in the trace sits just above the floor")
+    out["period_minus_profiler_floor_us"] = raw - floor
+    out.pop("period_corrected_us", None); out.pop("period_corrected_frac_of_8TBps", None); out.pop("period_corrected_over_bench_us_per_step", None)
+    cal.pop("per_dispatch_overhead_us", None); cal.pop("how", None)
     if bench_json and os.path.exists(bench_json):
         for line in open(bench_json):
             if line.startswith("{"):
                 d = json.loads(line)
                 out["bench_line_without_profiler"] = {"us_per_step": d["ms_per_step"] * 1e3, "kernel_us_hip_events": d["roofline"]["kernel_ms"] * 1e3,
                                                       "frac_survey_bytes": d["roofline"].get("frac_survey_bytes")}
-                out["period_corrected_over_bench_us_per_step"] = (raw - overhead) / (d["ms_per_step"] * 1e3)
-    print(json.dumps(out, indent=1))
+    if "bench_line_without_profiler" in out:
+        out["period_over_unprofiled_bench_us_per_step"] = raw / out["bench_line_without_profiler"]["us_per_step"]
+    return out
 
 
 if __name__ == "__main__":
@@ -113,5 +126,7 @@ if __name__ == "__main__":
         run()
     elif len(sys.argv) >= 6 and sys.argv[1] == "combine":
         combine(*sys.argv[2:7])
+    elif len(sys.argv) == 3 and sys.argv[1] == "restate":      # re-derive the reading from an existing JSON
+        print(json.dumps(restate(json.load(open(sys.argv[2]))), indent=1))
     else:
         sys.exit(__doc__)
