@@ -298,7 +298,10 @@ int dronesim_advantage(const float *G, const float *V, const int32_t *nbr_idx, c
  * episode counters, so a captured hipGraph draws fresh numbers on every replay.                      */
 typedef struct DroneMlp {
     int32_t N, d_in, h1, h2, nout;
-    int32_t out_kind;       /* 0 identity, 1 softmax, 2 tanh(first half) + sigmoid(second half) */
+    int32_t out_kind;       /* 0 identity, 1 softmax, 2 tanh(first half) + sigmoid(second half).  Accuracy contract of kinds 1 / 2
+                             * and of the sampling (round 5 on): the activations use the hardware's 1-ulp exp2 / rcp / log2 / sqrt /
+                             * sin / cos -- ABSOLUTE error <= 1e-6 per output (tanh as 1 - 2 / (e^2y + 1): no relative accuracy
+                             * for |y| << 1), so sampled actions are reproducible run to run but not bit-comparable with a libm build */
     int32_t sample_kind;    /* 0 none, 1 categorical -> unit-circle action, 2 Gaussian          */
     int32_t w2_layout;      /* 0: w2 = [N][h1][h2] (the reference's layout transposed, like w1 / w3);
                              * 1: w2 = float32 matrix-core fragments [N][ceil(h2/32)][ceil(h1/16)][2][64][4] with
@@ -331,7 +334,10 @@ typedef struct DroneMlpBf16 {
      * they were split; the kernel multiplies the layer's accumulators by 1 / wscale[i][l] (exact) before the bias-free
      * part meets the next layer.  A float16 part below 2^-14 is subnormal and keeps an ABSOLUTE 2^-24: an unscaled weight
      * of 0.05 is represented to 6e-7 of itself instead of 2^-22, which large activations multiply -- scaled so that the
-     * layer's largest weight sits near 2^14, every weight keeps its 22 bits (round 5).                              */
+     * layer's largest weight sits near 2^14, every weight keeps its 22 bits (round 5).  The factors live in DEVICE memory,
+     * so the entry point cannot validate them: anything but a (normal) power of two makes the inverse inexact.
+     * ABI NOTE: this field was appended in 0.5.0 -- a caller built against the 0.4.0 header passes a SHORTER struct and
+     * must be rebuilt (dronesim_version() >= 500) before it calls dronesim_mlp_forward_f16x2.                         */
     const float *wscale;
 } DroneMlpBf16;
 int dronesim_mlp_forward_bf16(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,

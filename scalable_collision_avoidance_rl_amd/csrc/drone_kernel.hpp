@@ -442,13 +442,21 @@ template <int GEO> struct GeoTraits {
         const int want = GEO == kBlock1024 ? 1 : (GEO == kSym64 && !is_rollout(mode)) ? kSymStepWaves
                                                                           : ((GEO == kBlock256 || GEO == kBlockU256) && !is_rollout(mode)) ? ((epi || far) ? kBlockStepWavesEpi : kBlockStepWaves)
                                      : (GEO == kBlockU256 && epi) ? kBlockRolloutEpiWaves
-                                     : (GEO == kPacked && epi && !far) ? kPackedRolloutEpiWaves : 4;
+                                     : (GEO == kPacked && epi && !far) ? kPackedRolloutEpiWaves : 4;   // (rollouts AND the packed step
+        // kernels of the episode layer: the latter were not the reason for the 168-register budget, but measured faster with it too --
+        // C2's graded step kernel 4.29 -> 4.19 us -- and stay included on purpose)
         const int cap = k <= 2 ? 8 : k <= 4 ? (((far || epi) && GEO == kBlock256 && !is_rollout(mode)) ? 5 : 6) : 4;   // (k = 3 / 4, FAR or episode layer: 8-12 B of spills at 80 registers)
         return want < cap ? want : cap;
     }
     static constexpr bool kWaveLocal = GEO == kPacked || GEO == kSym64;
 };
 
+// cells per axis of the generic bucket tables: ONE predicate for the kernel's carve-up and the host's LDS size (dronesim.hip).
+// Single-step launches of the workgroup-per-env geometries of up to 256 agents take kCellsBlock (see there), everything else kCells.
+__host__ __device__ constexpr int bucket_cells(int geo, bool rollout)
+{
+    return ((geo == kBlock256 || geo == kBlockU256) && !rollout) ? kCellsBlock : kCells;
+}
 // workgroup-per-env geometries: float2 entries of the position tile (N, the over-read slack, even for 16-byte alignment)
 __host__ __device__ constexpr int block_pos_entries(int N) { return (N + kPad + 1) & ~1; }
 // kSym64's LDS block per wave: [64 positions][staging: 64 x (z row + Ni row)][x cells | y cells] -- see the carve-up
@@ -724,7 +732,7 @@ __global__ void __launch_bounds__(GeoTraits<GEO>::kMaxThreads, GeoTraits<GEO>::m
     // fused rollouts keep 64 -- the candidate list's cells are 1.4 reaches wide, 65 of them at G = 256, and the tables are
     // zeroed at every rebuild: 128 cells measured +0.4 ... +0.9 % there, profiles/r5_abtest_block_cells.log)
     // (N > 256 keeps 64 as well: 16 words of 128 cells on two axes are 32 KiB of an LDS tile that N = 1024 with k = 8 fills)
-    constexpr int NCELL = ((GEO == kBlock256 || GEO == kBlockU256) && !is_rollout(MODE)) ? kCellsBlock : kCells;
+    constexpr int NCELL = bucket_cells(GEO, is_rollout(MODE));
     unsigned long long *sbt = sbt_all + (size_t)slot * (2 * NCELL) * W;                    // this lane's env
     // tail (episode bookkeeping): per-wave partial reward sums [nwaves][2], then the sampling tables of the in-kernel
     // reset, [epb][samp_tbl] x (node, owner)

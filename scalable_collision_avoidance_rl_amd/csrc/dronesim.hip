@@ -547,7 +547,7 @@ size_t drone_lds_bytes(const Geometry &g, int N, int k, int zc = 2, bool rollout
     b += sizeof(unsigned) * nwaves * kWave * (size_t)(zc + 1) * (size_t)(k + 1);   // z (zc words) + Ni (1 word) per slot and lane
     // bucket filter tables: [2 axes][64 cells][words] per env slot, or kSym64's per-wave rows (whichever is larger)
     const size_t slots = g.P > 0 ? (size_t)g.epb : 1, words = g.P > 0 ? 1 : nwaves;
-    size_t generic = (g.P > 0 && N < kBucketMinN) ? 0 : sizeof(unsigned long long) * slots * 2 * ((g.P > 0 || rollout || g.threads > 256) ? kCells : kCellsBlock) * words;
+    size_t generic = (g.P > 0 && N < kBucketMinN) ? 0 : sizeof(unsigned long long) * slots * 2 * (size_t)bucket_cells(g.geo, rollout) * words;
     if (g.P == 0 && samp > generic) generic = samp;
     const size_t sym = g.P > 0 ? sizeof(ulonglong2) * nwaves * kBucketRows : 0;
     b += generic > sym ? generic : sym;

@@ -1108,9 +1108,11 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
         const float *wsp = a.wscale + 3 * (size_t)agent;
         const float ws3 = wsp[2];
         ws1 = wsp[0]; ws2 = wsp[1];
-        wi1 = __uint_as_float(0x7f000000u - __float_as_uint(ws1));    // 2^-e from 2^e (normal powers of two: checked on the host side)
-        wi2 = __uint_as_float(0x7f000000u - __float_as_uint(ws2));
-        wi3 = __uint_as_float(0x7f000000u - __float_as_uint(ws3));
+        // 1 / factor by v_rcp_f32: EXACT for the powers of two include/dronesim.h asks for (a device-side pointer cannot be checked by
+        // the host entry point; exponent arithmetic on the bit pattern, as in round 5, was only right for normal powers of two)
+        wi1 = __builtin_amdgcn_rcpf(ws1);
+        wi2 = __builtin_amdgcn_rcpf(ws2);
+        wi3 = __builtin_amdgcn_rcpf(ws3);
     }
     if (kTrace && a.trace && lane == 0) {                          // shader clock and the 100 MHz clock at entry
         a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + 0] = __builtin_amdgcn_s_memtime();
