@@ -1351,6 +1351,252 @@ __global__ void __launch_bounds__(256, TILES <= 2 ? 2 : 1) mlp3_split_kernel(con
 #undef X3_PIN
 #undef X3_RING_READ
 
+// ---------------------------------------------------------------------------------------------------------
+// Exact float32, ROW-TILE ownership (round 6; DroneMlp.w2_layout = 2): the register-fused formulation of the split kernels on
+// v_mfma_f32_32x32x2_f32, with the work split the other way round.  A wave owns 32 env rows of one agent and ALL output chunks
+// of layer 2 for them (up to kRtChunks = 7 accumulator tiles = 112 registers per pass; h2 > 224 takes two passes and recomputes
+// layer 1 in the second: 52 of 2900 matrix instructions at h = 400), so
+//   * nothing is computed twice across waves and every wave issues the same number of matrix instructions (whole chunks dealt
+//     to waves leave 13 / 10 / 7 chunks at 4-3-3-3 / 3-3-2-2 / 2-2-2-1: 0.70 / 0.70 / 0.62 of the matrix peak at best);
+//   * layers 1 -> 2 -> 3 meet in REGISTERS: D^T[feature][row] of v_mfma_f32_32x32x2_f32 puts feature 8 (r >> 2) + 4 (lane >> 5)
+//     + (r & 3) of row (lane & 31) into register r, and register r of the two lane halves IS the B operand of k-step r of the
+//     next layer once the weights' k order is permuted to match on the host (policies.py: pack_f32_rowtile_stream) -- no
+//     activation touches LDS, no barrier after the prologue, layer 3 is complete inside the wave;
+//   * the vector ALU -- which the float32 matrix instructions run on -- sees 16 v_max per 32-feature chunk and nothing else in the
+//     loop: weights travel global -> LDS by DMA into a ring PRIVATE to the wave (4 blocks of 4 KiB = the sixteen A operands of
+//     one (in-chunk, out-chunk) pair, four blocks ahead) and LDS -> registers as one ds_read_b128 per four matrix instructions.
+// Matrix instructions per wave and 32 rows: 840 / 1740 / 2912 at h = 200 / 300 / 400 = 0.77 / 0.87 / 0.88 of the peak if none stalls.
+// One agent's stream, in consumption order (blocks of 4 pieces of 1 KiB = [64 lanes][4 floats]):
+//   per pass p (output chunks S_p):  for c1: L1(c1), L2(c1, c2) for c2 in S_p;  then L3(c2) for c2 in S_p;  kRtPad zero blocks.
+//   L1(c1): piece 0 = W1[2 r + half][32 c1 + i], r = 0..3; piece 1 = the same for r = 4..6, then b1[32 c1 + i] (lanes < 32);
+//   L2(c1, c2): piece q = W2[32 c1 + 8 q + 4 half + j][32 c2 + i], j = 0..3;   L3(c2): piece q = W3[32 c2 + 8 q + 4 half + j][i]
+//   (lane = 32 half + i; zero beyond d_in / h1 / h2 / nout).
+constexpr int kRtChunks = 7, kRtRing = 4, kRtPad = kRtRing, kRtRows = 128;
+__host__ __device__ constexpr int rt_passes(int nc2) { return (nc2 + kRtChunks - 1) / kRtChunks; }
+__host__ __device__ constexpr int rt_per_pass(int nc2) { return (nc2 + rt_passes(nc2) - 1) / rt_passes(nc2); }
+
+struct MArgsR {
+    int E, N, d_in, h1, h2, nout, nc1, nc2, blocks;
+    const float *x, *ws, *b2, *b3;
+    FinishArgs fin;
+    unsigned rb_magic;
+};
+
+#define RT_PIN() __builtin_amdgcn_sched_barrier(0)
+
+__global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, int N, int d_in, const MArgsR rest)
+{
+    MArgsR a = rest;
+    a.x = x; a.E = E; a.N = N; a.d_in = d_in;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int agent, row_block;
+    xcd_work_item((a.E + kRtRows - 1) / kRtRows, agent, row_block, a.rb_magic);
+    const int e0 = row_block * kRtRows + 32 * wave;                // this wave's 32 env rows
+    const int half = lane >> 5;
+    const int nc1 = a.nc1, nc2 = a.nc2, ks1 = (a.d_in + 1) >> 1;
+    float *sb2 = reinterpret_cast<float *>(smem);                  // b2, zero padded to whole chunks
+    char *ring = smem + ((nc2 * 32 * 4 + 15) & ~15) + wave * (kRtRing * 4096);
+
+    for (int i = tid; i < nc2 * 32; i += 256) {                    // (clamped address, masked value: no branch around the load)
+        const float v = a.b2[(size_t)agent * a.h2 + min(i, a.h2 - 1)];
+        sb2[i] = __uint_as_float(__float_as_uint(v) & (i < a.h2 ? 0xffffffffu : 0u));
+    }
+    // the x operand of layer 1: k-step r = inputs 2 r + half of row (lane & 31)
+    float xb[7];
+    {
+        const int e = min(e0 + (lane & 31), a.E - 1);
+        const float *xr = a.x + ((size_t)e * a.N + agent) * a.d_in;
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int k = 2 * r + half;
+            const float v = xr[min(k, a.d_in - 1)];
+            xb[r] = __uint_as_float(__float_as_uint(v) & (k < a.d_in ? 0xffffffffu : 0u));
+        }
+    }
+    // the output stage's inputs: four lanes per env row, two rounds of 16 rows
+    uint32_t tval[2] = {0u, 0u}, epval[2] = {0u, 0u};
+    float b3v[2][kQ];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = e0 + 16 * it + (lane >> 2);
+        if (e < a.E && a.fin.sample_kind != 0) {
+            if (a.fin.t_dev) tval[it] = (uint32_t)a.fin.t_dev[e];
+            if (a.fin.episode_dev) epval[it] = (uint32_t)a.fin.episode_dev[e];
+        }
+#pragma unroll
+        for (int i = 0; i < kQ; ++i) {
+            const int j = (lane & 3) + 4 * i;
+            const float v = a.b3[(size_t)agent * a.nout + min(j, a.nout - 1)];
+            b3v[it][i] = j < a.nout ? v : 0.0f;
+        }
+    }
+    __syncthreads();                                               // b2 is in LDS; the only barrier of the kernel
+    if (e0 >= a.E) return;                                         // a wave without rows (ragged last workgroup)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every load above has landed: from here vmcnt counts DMA pieces only
+
+    // ---- the weight stream.  Everything about it is scalar except the lane's 16-byte slot: the float32 matrix instructions run
+    // on the vector ALUs, so every vector instruction in the loop is matrix time lost -- the DMA requests are issued by name with a
+    // scalar base and a constant 32-bit lane offset (hipcc forms 64-bit per-lane addresses with two v_lshl_add_u64 per request), and
+    // the ring reads by name with counted waits (hipcc waits for ALL outstanding LDS reads in front of a block's first instruction).
+    const unsigned long long sbase0 = reinterpret_cast<unsigned long long>(a.ws) + (unsigned long long)agent * a.blocks * 4096ull;
+    const unsigned voff = (unsigned)lane * 16u;                    // this lane's slot of a 1-KiB piece (global and LDS alike)
+    const unsigned ring_a = lds_addr(ring);
+    const unsigned rd_a = ring_a + voff;                           // LDS address of this lane's slot in ring block 0, piece 0
+    int cur = 0;                                                   // block being consumed; its ring slot = cur & 3
+    auto dma = [&](int blk, int q) {                               // piece q of stream block blk -> its ring slot
+        const unsigned long long src = sbase0 + (unsigned long long)(unsigned)blk * 4096ull + (unsigned)q * 1024u;
+        const unsigned dst = ring_a + (unsigned)(blk & (kRtRing - 1)) * 4096u + (unsigned)q * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+    };
+    f32x4 w[4];                                                    // the current block's sixteen A operands
+#pragma unroll 1
+    for (int b = 0; b < kRtRing; ++b) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma(b, q);
+    }
+    asm volatile("s_waitcnt vmcnt(12)\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+                 "ds_read_b128 %3, %4 offset:3072" : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(rd_a) : "memory");
+    // one group = the four matrix instructions of piece q (`mf`) -- the piece was requested from LDS a block ago: at most three
+    // younger reads may still be out -- then the piece's ring slot is refilled with block cur + 4, and piece q of block cur + 1
+    // (landed: twelve DMA requests were issued behind it) takes its place in the registers
+    auto group = [&](auto Q, auto &&mf) {
+        constexpr int q = decltype(Q)::value;
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w[q]) :: "memory");
+        mf(w[q]);
+        RT_PIN();
+        dma(cur + kRtRing, q);
+        const unsigned ra = rd_a + (unsigned)((cur + 1) & (kRtRing - 1)) * 4096u;
+        asm volatile("s_waitcnt vmcnt(12)\n\tds_read_b128 %0, %1 offset:%2" : "=v"(w[q]) : "v"(ra), "n"(q * 1024) : "memory");
+        RT_PIN();
+    };
+    typedef std::integral_constant<int, 0> Q0; typedef std::integral_constant<int, 1> Q1;
+    typedef std::integral_constant<int, 2> Q2; typedef std::integral_constant<int, 3> Q3;
+    auto nothing = [](const f32x4 &) {};
+
+    f32x16 y = {0}, y1 = {0};
+    const float one = lane < 32 ? 1.0f : 0.0f;
+    const int passes = rt_passes(nc2), per = rt_per_pass(nc2);
+    for (int p = 0; p < passes; ++p) {
+        const int c2_0 = p * per, npc = min(per, nc2 - c2_0);      // this pass's output chunks (wave-uniform)
+        f32x16 acc2[kRtChunks];
+#pragma unroll
+        for (int i = 0; i < kRtChunks; ++i) acc2[i] = bias_tile(sb2 + min(c2_0 + i, nc2 - 1) * 32, lane);
+        for (int c1 = 0; c1 < nc1; ++c1) {
+            // layer 1 of chunk c1: K = d_in <= 14, then the bias on one more matrix instruction (A = b1 in lanes 0..31, B = 1 there)
+            f32x16 a1 = {0};
+            group(Q0{}, [&](const f32x4 &v) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j < ks1) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], xb[j], a1, 0, 0, 0);
+            });
+            group(Q1{}, [&](const f32x4 &v) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) if (4 + j < ks1) a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], xb[4 + j], a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3], one, a1, 0, 0, 0);
+            });
+            group(Q2{}, nothing);
+            group(Q3{}, nothing);
+            ++cur;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a1[r] = fmaxf(a1[r], 0.0f);
+            // layer 2: every output chunk of the pass takes this chunk's 32 features -- 16 k-steps, B = register r of a1.  Group q holds
+            // the features 8 q .. 8 q + 7 of the chunk: the groups of a ragged last chunk that hold none are skipped (h = 400 / 300 /
+            // 200 end in chunks of 16 / 12 / 8 features: 8 / 8 / 12 of the 16 instructions of each of that chunk's blocks)
+            const int kv = a.h1 - 32 * c1;                     // features of this in-chunk (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < kRtChunks; ++i) {
+                if (i < npc) {
+                    group(Q0{}, [&](const f32x4 &v) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], a1[j], acc2[i], 0, 0, 0);
+                    });
+                    group(Q1{}, [&](const f32x4 &v) {
+                        if (kv > 8) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], a1[4 + j], acc2[i], 0, 0, 0);
+                        }
+                    });
+                    group(Q2{}, [&](const f32x4 &v) {
+                        if (kv > 16) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], a1[8 + j], acc2[i], 0, 0, 0);
+                        }
+                    });
+                    group(Q3{}, [&](const f32x4 &v) {
+                        if (kv > 24) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], a1[12 + j], acc2[i], 0, 0, 0);
+                        }
+                    });
+                    ++cur;
+                }
+            }
+        }
+        // layer 3 from the finished chunks of this pass: two accumulation chains (even / odd chunks) that are added at the end --
+        // half the roundings in a row on the outputs' own scale (every instruction rounds once; the 16-column instruction of the
+        // LDS-staged kernel takes four products per rounding, this one two)
+        auto layer3 = [&](f32x16 &yy, f32x16 &h, int kv3) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = fmaxf(h[r], 0.0f);
+            group(Q0{}, [&](const f32x4 &v) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yy = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], h[j], yy, 0, 0, 0);
+            });
+            group(Q1{}, [&](const f32x4 &v) {
+                if (kv3 > 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yy = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], h[4 + j], yy, 0, 0, 0);
+                }
+            });
+            group(Q2{}, [&](const f32x4 &v) {
+                if (kv3 > 16) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yy = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], h[8 + j], yy, 0, 0, 0);
+                }
+            });
+            group(Q3{}, [&](const f32x4 &v) {
+                if (kv3 > 24) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yy = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], h[12 + j], yy, 0, 0, 0);
+                }
+            });
+            ++cur;
+        };
+#pragma unroll
+        for (int i = 0; i < kRtChunks; ++i) {
+            if (i < npc) {
+                const int kv3 = a.h2 - 32 * (c2_0 + i);      // features of this chunk (the same skipping as in layer 2)
+                if (i & 1) layer3(y1, acc2[i], kv3); else layer3(y, acc2[i], kv3);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the output tile reuses the ring: no DMA may land late
+
+    // ---- output activation + sampling: the wave's 32 x nout tile through its own LDS region, four lanes per env row
+    float *st = reinterpret_cast<float *>(ring);                   // [32 rows][33]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[(lane & 31) * 33 + cd_row(r, lane)] = y[r] + y1[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = 16 * it + (lane >> 2), part = lane & 3;
+        const int e = e0 + row;
+        if (e < a.E) {
+            float yv[kQ];
+#pragma unroll
+            for (int i = 0; i < kQ; ++i) {
+                const int j = part + 4 * i;
+                yv[i] = j < a.nout ? st[row * 33 + j] + b3v[it][i] : 0.0f;
+            }
+            finish_quad(a.fin, yv, e, agent, part, tval[it], epval[it]);
+        }
+    }
+}
+#undef RT_PIN
+
 // > 64 KiB of dynamic LDS must be opted into once per (kernel, device): a bit mask of device ordinals per kernel,
 // guarded by a mutex (the library may be driven from several host threads / devices of one process)
 int enable_big_lds(const void *kernel, unsigned long long (&opted)[4], std::mutex &mu, const char *what)
@@ -1518,6 +1764,14 @@ int mlp_forward_split(const char *what, const DroneMlpBf16 *m, const float *x, f
     return launch_split<S, 2>(a, m->N, static_cast<hipStream_t>(stream));
 }
 
+// blocks (4 KiB each) of one agent's row-tile weight stream, zero padding included (DroneMlp.w2_layout = 2; see mlp3_rt_kernel)
+extern "C" int dronesim_mlp_rt_blocks(int h1, int h2)
+{
+    if (h1 < 1 || h2 < 1) return 0;
+    const int nc1 = (h1 + 31) / 32, nc2 = (h2 + 31) / 32;
+    return rt_passes(nc2) * nc1 + nc1 * nc2 + nc2 + kRtPad;
+}
+
 extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                                            uint64_t seed, uint64_t counter, int64_t env_base,
                                            const int32_t *t, const int32_t *episode, int E, void *stream)
@@ -1539,9 +1793,38 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL argument");
     const int rc = check_mlp("f32", m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
     if (rc) return rc;
+    if (m->w2_layout == 2) {
+        // the row-tile stream (round 6): w2 = [N][dronesim_mlp_rt_blocks(h1, h2)][4][64][4] float32 holding W1, b1, W2 and W3 in the
+        // kernel's consumption order; w1 / b1 / w3 are not read
+        if (!m->w2 || !m->b2 || !m->b3) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
+        if (m->d_in > 14) return dronesim_fail(DRONESIM_EUNSUPPORTED, "dronesim_mlp_forward: w2_layout = 2 needs d_in <= 14");
+        if ((reinterpret_cast<uintptr_t>(m->w2) & 15u) != 0)
+            return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: the row-tile stream (w2_layout = 2) must be 16-byte aligned");
+        if (E == 0) return DRONESIM_OK;
+        MArgsR r{};
+        r.E = E; r.N = m->N; r.d_in = m->d_in; r.h1 = m->h1; r.h2 = m->h2; r.nout = m->nout;
+        r.nc1 = (m->h1 + 31) / 32; r.nc2 = (m->h2 + 31) / 32;
+        r.blocks = dronesim_mlp_rt_blocks(m->h1, m->h2);
+        r.x = x; r.ws = m->w2; r.b2 = m->b2; r.b3 = m->b3;
+        r.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
+        const size_t lds = (((size_t)r.nc2 * 32 * 4 + 15) & ~(size_t)15) + 4 * (size_t)kRtRing * 4096;
+        {
+            static std::mutex mu;
+            static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
+            const int lrc = enable_big_lds(reinterpret_cast<const void *>(mlp3_rt_kernel), opted, mu, "mlp3_rt_kernel");
+            if (lrc) return lrc;
+        }
+        const unsigned rb = (unsigned)((E + kRtRows - 1) / kRtRows);
+        const dim3 grid(rb * m->N);
+        r.rb_magic = div_magic(grid.x, rb);
+        hipLaunchKernelGGL(mlp3_rt_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), r.x, r.E, r.N, r.d_in, r);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+        return DRONESIM_OK;
+    }
     if (!m->w1 || !m->b1 || !m->w2 || !m->b2 || !m->w3 || !m->b3)
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
-    if (m->w2_layout != 0 && m->w2_layout != 1) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: w2_layout must be 0 or 1");
+    if (m->w2_layout != 0 && m->w2_layout != 1) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: w2_layout must be 0, 1 or 2");
     if (m->w2_layout == 1 && (reinterpret_cast<uintptr_t>(m->w2) & 15u) != 0)     // read with 16-byte vector loads
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: fragment-packed w2 (w2_layout = 1) must be 16-byte aligned");
     if (E == 0) return DRONESIM_OK;

@@ -181,6 +181,54 @@ def pack_f32_fragments(w):
     return frag.reshape(n, nc, ns, 2, 64, 4).contiguous()
 
 
+RT_CHUNKS, RT_PAD = 7, 4          # csrc/policy.hip: kRtChunks (output chunks a wave keeps per pass), kRtPad (zero blocks behind a stream)
+
+
+def pack_f32_rowtile_stream(w1, b1, w2, w3):
+    """[N, d_in, h1], [N, h1], [N, h1, h2], [N, h2, nout] float32 -> the weight stream of the row-tile exact-f32 kernel
+    (`DroneMlp.w2_layout = 2`, csrc/policy.hip: mlp3_rt_kernel): ``[N, blocks, 4, 64, 4]`` float32, blocks of four 1-KiB pieces
+    ``[64 lanes][4 floats]`` (lane = 32 half + i) in the kernel's consumption order:
+
+        per pass p (output chunks S_p):  for c1: L1(c1), L2(c1, c2) for c2 in S_p;  then L3(c2) for c2 in S_p;  RT_PAD zero blocks
+        L1(c1):      piece 0 = W1[2 r + half, 32 c1 + i] for r = 0..3;  piece 1 = the same for r = 4..6, then b1[32 c1 + i] (lanes < 32)
+        L2(c1, c2):  piece q = W2[32 c1 + 8 q + 4 half + j, 32 c2 + i],  j = 0..3
+        L3(c2):      piece q = W3[32 c2 + 8 q + 4 half + j, i]
+    (zero beyond d_in / h1 / h2 / nout).  The k order 8 q + 4 half + j is the order in which a lane of the float32 matrix
+    instruction's accumulator tile holds its features, so each layer's output feeds the next one from registers."""
+    import torch
+    n, d_in, h1 = w1.shape
+    h2, nout = w3.shape[1], w3.shape[2]
+    if d_in > 14 or nout > 32:
+        raise ValueError("the row-tile stream needs d_in <= 14 and nout <= 32")
+    nc1, nc2 = (h1 + 31) // 32, (h2 + 31) // 32
+    dev = w1.device
+    W1 = torch.zeros(n, 16, nc1 * 32, device=dev); W1[:, :d_in, :h1] = w1
+    B1 = torch.zeros(n, nc1 * 32, device=dev); B1[:, :h1] = b1
+    W2 = torch.zeros(n, nc1 * 32, nc2 * 32, device=dev); W2[:, :h1, :h2] = w2
+    W3 = torch.zeros(n, nc2 * 32, 32, device=dev); W3[:, :h2, :nout] = w3
+    # L1 blocks [n, nc1, 4 pieces, 64 lanes, 4]: k = 2 r + half with r = 4 piece + j
+    l1 = torch.zeros(n, nc1, 4, 2, 32, 4, device=dev)                            # [.., piece, half, i, j]
+    kk = W1.view(n, 8, 2, nc1, 32)                                               # [n, r, half, c1, i]
+    l1[:, :, 0] = kk[:, 0:4].permute(0, 3, 2, 4, 1)                              # r = 0..3 -> j
+    l1[:, :, 1, :, :, 0:3] = kk[:, 4:7].permute(0, 3, 2, 4, 1)                   # r = 4..6
+    l1[:, :, 1, 0, :, 3] = B1.view(n, nc1, 32)                                   # bias in lanes 0..31 (half 0)
+    l1 = l1.reshape(n, nc1, 4, 64, 4)
+    # L2 blocks [n, c1, c2, q, half, i, j]: k = 32 c1 + 8 q + 4 half + j
+    l2 = W2.view(n, nc1, 4, 2, 4, nc2, 32).permute(0, 1, 5, 2, 3, 6, 4).reshape(n, nc1, nc2, 4, 64, 4)
+    l3 = W3.view(n, nc2, 4, 2, 4, 32).permute(0, 1, 2, 3, 5, 4).reshape(n, nc2, 4, 64, 4)
+    passes = (nc2 + RT_CHUNKS - 1) // RT_CHUNKS
+    per = (nc2 + passes - 1) // passes
+    seq = []
+    for p in range(passes):
+        chunks = range(p * per, min(nc2, (p + 1) * per))
+        for c1 in range(nc1):
+            seq.append(l1[:, c1])
+            seq += [l2[:, c1, c2] for c2 in chunks]
+        seq += [l3[:, c2] for c2 in chunks]
+    seq += [torch.zeros_like(l1[:, 0])] * RT_PAD
+    return torch.stack(seq, dim=1).contiguous()
+
+
 class BatchedMLP:
     def __init__(self, w1, b1, w2, b2, w3, b3, out_kind, sample_kind, device=None, seed=0, precision="f32", pack_w2=True):
         """w1 [N,d_in,h1], b1 [N,h1], w2 [N,h1,h2], b2 [N,h2], w3 [N,h2,nout], b3 [N,nout] (float32).
@@ -189,8 +237,10 @@ class BatchedMLP:
         activations on the 16-bit matrix instructions (six / three partial products); f16x2 is the faster one and
         needs every weight, input and hidden activation below 65504 in magnitude; ``"bf16"`` runs weights and
         activations in plain bfloat16 with float32 accumulation (~1e-2 relative agreement, fastest).
-        ``pack_w2`` (f32 only): hand layer 2's weights to the kernel as matrix-core fragments (`pack_f32_fragments`,
-        the fast path); False keeps the [N, h1, h2] array of the plain C ABI (`DroneMlp.w2_layout = 0`).
+        ``pack_w2`` (f32 only): True (default) hands the kernel ONE packed stream of all three layers (`pack_f32_rowtile_stream`,
+        `DroneMlp.w2_layout = 2`: the row-tile kernel of round 6; d_in <= 14), "fragments" layer 2 as matrix-core fragments
+        (`pack_f32_fragments`, `w2_layout = 1`: the kernel of rounds 3-5); False keeps the [N, h1, h2] array of the plain C ABI
+        (`w2_layout = 0`).
         NOTE: the packed images are SNAPSHOTS of the weights: after an in-place update of ``w1 .. b3`` call
         `refresh_weights()` (re-packs into the same device buffers)."""
         import torch
@@ -216,8 +266,18 @@ class BatchedMLP:
         m.b2, m.w3, m.b3 = self.b2.data_ptr(), self.w3.data_ptr(), self.b3.data_ptr()
         self._m = m
         self.precision = precision
-        if precision == "f32" and pack_w2:
-            # layer 2 (all but a few per cent of the arithmetic) reads its weights as matrix-core fragments
+        self._rowtile = False
+        if precision == "f32" and pack_w2 == "fragments":
+            # round 3-5 fast path: layer 2 reads its weights as matrix-core fragments (`DroneMlp.w2_layout = 1`)
+            self._w2p = pack_f32_fragments(self.w2)
+            m.w2, m.w2_layout = self._w2p.data_ptr(), 1
+        elif precision == "f32" and pack_w2 and self.d_in <= 14:
+            # round 6: ONE stream holding all three layers in the row-tile kernel's consumption order (`DroneMlp.w2_layout = 2`)
+            self._w2p = pack_f32_rowtile_stream(self.w1, self.b1, self.w2, self.w3)
+            assert self._w2p.shape[1] == int(self._lib.dronesim_mlp_rt_blocks(self.h1, self.h2))
+            m.w2, m.w2_layout = self._w2p.data_ptr(), 2
+            self._rowtile = True
+        elif precision == "f32" and pack_w2:
             self._w2p = pack_f32_fragments(self.w2)
             m.w2, m.w2_layout = self._w2p.data_ptr(), 1
         if precision == "bf16":
@@ -262,7 +322,8 @@ class BatchedMLP:
                 getattr(self, name).copy_(self._torch.as_tensor(val, dtype=self._torch.float32))
         if self.precision == "f32":
             if getattr(self, "_w2p", None) is not None:
-                self._w2p.copy_(pack_f32_fragments(self.w2))
+                self._w2p.copy_(pack_f32_rowtile_stream(self.w1, self.b1, self.w2, self.w3) if self._rowtile
+                                else pack_f32_fragments(self.w2))
         elif self.precision == "bf16":
             nc1, nc2 = (self.h1 + 31) // 32, (self.h2 + 31) // 32
             self._w1p.copy_(pack_bf16_fragments(self.w1, 1, nc1))

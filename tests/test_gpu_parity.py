@@ -1067,8 +1067,8 @@ def test_batched_policy_split_precisions_hold_the_float32_bar(torch, prec):
 
 def test_policy_shape_fuzz_all_precisions(torch):
     """Seeded random network shapes (d_in 1..16, h1 / h2 1..512 incl. non-multiples of 32 and fewer chunks than waves,
-    nout 1..32, 1..6 agents, ragged E incl. 1) through every policy arithmetic against float64: exact-f32 (layer 2 on
-    fragment-packed weights and on the plain [N, h1, h2] array of the C ABI), bf16x3 and f16x2 at the 1e-5 bar, plain
+    nout 1..32, 1..6 agents, ragged E incl. 1) through every policy arithmetic against float64: exact-f32 (the row-tile stream,
+    layer 2 on fragment-packed weights and on the plain [N, h1, h2] array of the C ABI), bf16x3 and f16x2 at the 1e-5 bar, plain
     bf16 at its own 3e-2."""
     import os
     from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
@@ -1091,8 +1091,10 @@ def test_policy_shape_fuzz_all_precisions(torch):
         ref = (y if kind == 0 else torch.softmax(y, -1) if kind == 1
                else torch.cat([torch.tanh(y[..., :2]), torch.sigmoid(y[..., 2:])], -1)).numpy()
         tag = f"policy fuzz#{it} d={d} h1={h1} h2={h2} nout={nout} kind={kind} N={N} E={E}"
-        for prec in ("f32", "f32-w2-unpacked", "bf16x3", "f16x2", "bf16"):
+        # ("f32" = the row-tile stream of round 6 for d_in <= 14, else the fragment-packed layer 2; the other two layouts by name)
+        for prec in ("f32", "f32-fragments", "f32-w2-unpacked", "bf16x3", "f16x2", "bf16"):
             pol = (BatchedMLP(*w, out_kind=kind, sample_kind=0, precision="f32", pack_w2=False) if prec == "f32-w2-unpacked"
+                   else BatchedMLP(*w, out_kind=kind, sample_kind=0, precision="f32", pack_w2="fragments") if prec == "f32-fragments"
                    else BatchedMLP(*w, out_kind=kind, sample_kind=0, precision=prec))
             out = host(pol.forward(x.cuda()))
             if prec == "bf16":

@@ -199,10 +199,56 @@ def test_mlp_forward_validates_w2_layout_before_any_hip_call():
     m.N, m.d_in, m.h1, m.h2, m.nout, m.out_kind, m.sample_kind = 2, 6, 40, 72, 4, 0, 0
     one = C.c_void_p(16)                                          # any non-NULL address: validation never dereferences
     m.w1 = m.b1 = m.w2 = m.b2 = m.w3 = m.b3 = one
-    for layout, want in ((0, _native.OK), (1, _native.OK), (2, _native.EINVAL), (-1, _native.EINVAL)):
+    for layout, want in ((0, _native.OK), (1, _native.OK), (2, _native.OK), (3, _native.EINVAL), (-1, _native.EINVAL)):
         m.w2_layout = layout
         assert lib.dronesim_mlp_forward(C.byref(m), one, None, None, None, 0, 0, 0, None, None, 0, None) == want   # E = 0
     assert b"w2_layout" in lib.dronesim_last_error()
+    m.w2_layout, m.d_in = 2, 15                                   # the row-tile stream holds at most 14 inputs
+    assert lib.dronesim_mlp_forward(C.byref(m), one, None, None, None, 0, 0, 0, None, None, 0, None) == _native.EUNSUPPORTED
+    m.d_in, m.w2 = 6, C.c_void_p(20)                              # ... and must be 16-byte aligned
+    assert lib.dronesim_mlp_forward(C.byref(m), one, None, None, None, 0, 0, 0, None, None, 0, None) == _native.EINVAL
+
+
+def test_pack_f32_rowtile_stream_layout():
+    """`pack_f32_rowtile_stream` lays all three layers out as include/dronesim.h states for DroneMlp.w2_layout = 2, block by block in
+    the kernel's consumption order, and `dronesim_mlp_rt_blocks` counts the same blocks."""
+    import torch
+    from scalable_collision_avoidance_rl_amd import policies as P
+    lib = _native.lib()
+    g = torch.Generator().manual_seed(5)
+    for (n, d, h1, h2, no) in ((2, 6, 70, 250, 4), (1, 14, 32, 32, 16), (2, 3, 200, 200, 1), (1, 6, 400, 400, 4), (1, 5, 33, 449, 32)):
+        w1, b1 = torch.rand(n, d, h1, generator=g), torch.rand(n, h1, generator=g)
+        w2, w3 = torch.rand(n, h1, h2, generator=g), torch.rand(n, h2, no, generator=g)
+        st = P.pack_f32_rowtile_stream(w1, b1, w2, w3)
+        nc1, nc2 = (h1 + 31) // 32, (h2 + 31) // 32
+        passes = (nc2 + P.RT_CHUNKS - 1) // P.RT_CHUNKS
+        per = (nc2 + passes - 1) // passes
+        assert st.shape == (n, int(lib.dronesim_mlp_rt_blocks(h1, h2)), 4, 64, 4) and st.dtype == torch.float32 and st.is_contiguous()
+        el = lambda t, a, k, c: float(t[a, k, c]) if k < t.shape[1] and c < t.shape[2] else 0.0
+        rng = np.random.default_rng(1)
+        blk = 0
+        for p in range(passes):
+            chunks = range(p * per, min(nc2, (p + 1) * per))
+            for c1 in range(nc1):
+                B = st[:, blk]; blk += 1
+                for _ in range(12):
+                    a, lane, r = int(rng.integers(0, n)), int(rng.integers(0, 64)), int(rng.integers(0, 7))
+                    half, i = lane >> 5, lane & 31
+                    piece, j = (0, r) if r < 4 else (1, r - 4)
+                    assert float(B[a, piece, lane, j]) == el(w1, a, 2 * r + half, 32 * c1 + i)
+                    assert float(B[a, 1, lane, 3]) == (float(b1[a, 32 * c1 + i]) if half == 0 and 32 * c1 + i < h1 else 0.0)
+                    assert float(B[a, 2 + (r & 1), lane, j & 3]) == 0.0
+                for c2 in chunks:
+                    B = st[:, blk]; blk += 1
+                    for _ in range(12):
+                        a, lane, q, j = (int(rng.integers(0, m)) for m in (n, 64, 4, 4))
+                        assert float(B[a, q, lane, j]) == el(w2, a, 32 * c1 + 8 * q + 4 * (lane >> 5) + j, 32 * c2 + (lane & 31))
+            for c2 in chunks:
+                B = st[:, blk]; blk += 1
+                for _ in range(12):
+                    a, lane, q, j = (int(rng.integers(0, m)) for m in (n, 64, 4, 4))
+                    assert float(B[a, q, lane, j]) == el(w3, a, 32 * c2 + 8 * q + 4 * (lane >> 5) + j, lane & 31)
+        assert blk + P.RT_PAD == st.shape[1] and float(st[:, blk:].abs().max()) == 0.0
 
 
 def test_pack_f32_fragments_layout():
