@@ -312,19 +312,20 @@ typedef struct DroneMlp {
                              * 2: (0.6.0; d_in <= 14; what the host class BatchedMLP passes) w2 = ONE stream per agent holding
                              *    W1, b1, W2 and W3 in the consumption order of the row-tile kernel (a wave owns 32 env rows
                              *    and every output chunk; layers meet in registers): [N][B][4][64][4] float32 with
-                             *    B = dronesim_mlp_rt_blocks(h1, h2) blocks of four 1-KiB pieces [lane = 32 half + i][4]:
+                             *    B = dronesim_mlp_rt_blocks(h1, h2, nout) blocks of four 1-KiB pieces [lane = 32 half + i][4]:
                              *      passes P = ceil(C2 / 7), chunks per pass = ceil(C2 / P), C1 = ceil(h1/32), C2 = ceil(h2/32);
-                             *      per pass p (output chunks S_p): for c1 < C1: L1(c1), L2(c1, c2) for c2 in S_p; then L3(c2)
-                             *      for c2 in S_p; behind the last pass 4 zero blocks;
+                             *      per pass p (output chunks S_p): for c1 < C1: L1(c1), L2(c1, c2) for c2 in S_p; then -- nout > 4
+                             *      only -- L3(c2) for c2 in S_p; behind the last pass 4 zero blocks;
                              *      L1(c1): piece 0 = W1[2 r + half][32 c1 + i], r = 0..3; piece 1 = the same for r = 4..6,
                              *              then b1[32 c1 + i] in lanes < 32; pieces 2, 3 zero;
                              *      L2(c1, c2): piece q = W2[32 c1 + 8 q + 4 half + j][32 c2 + i], j = 0..3;
                              *      L3(c2):     piece q = W3[32 c2 + 8 q + 4 half + j][i]       (zero beyond d_in / h1 / h2 / nout).
-                             *    w1, b1, w3 are not read (may be NULL); b2, b3 as always.  Same arithmetic (float32 fmaf
-                             *    chains on the matrix cores) in a different summation order; 16-byte aligned.            */
+                             *    w1, b1 are not read (may be NULL); b2, b3 as always; w3 = the plain [N][h2][nout] array when
+                             *    nout <= 4 (layer 3 then runs on the vector ALU and the stream holds no L3 blocks), not read
+                             *    otherwise.  Same arithmetic (float32 fmaf chains) in a different summation order; 16-byte aligned. */
     const float *w1, *b1, *w2, *b2, *w3, *b3;
 } DroneMlp;
-int dronesim_mlp_rt_blocks(int h1, int h2);   /* blocks (4 KiB) per agent of the w2_layout = 2 stream                      */
+int dronesim_mlp_rt_blocks(int h1, int h2, int nout);   /* blocks (4 KiB) per agent of the w2_layout = 2 stream              */
 int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,
                          uint64_t seed, uint64_t counter, int64_t env_base,
                          const int32_t *t, const int32_t *episode, int E, void *stream);

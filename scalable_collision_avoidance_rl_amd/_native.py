@@ -135,7 +135,7 @@ def lib():
     L.dronesim_mlp_forward_f16x2.argtypes = L.dronesim_mlp_forward_bf16.argtypes
     L.dronesim_mlp_forward_f16x2.restype = C.c_int
     L.dronesim_mlp_bf16x3_stages.argtypes = [C.c_int, C.c_int]
-    L.dronesim_mlp_rt_blocks.argtypes = [C.c_int, C.c_int]
+    L.dronesim_mlp_rt_blocks.argtypes = [C.c_int, C.c_int, C.c_int]
     L.dronesim_mlp_bf16x3_stages.restype = C.c_int
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
     PC = C.POINTER(DroneEpisodeCtl)

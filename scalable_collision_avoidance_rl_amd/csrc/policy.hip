@@ -1378,12 +1378,19 @@ __host__ __device__ constexpr int rt_per_pass(int nc2) { return (nc2 + rt_passes
 struct MArgsR {
     int E, N, d_in, h1, h2, nout, nc1, nc2, blocks;
     const float *x, *ws, *b2, *b3;
+    const float *w3;                     // VL3: the plain [N][h2][nout] output layer (nout <= 4)
     FinishArgs fin;
     unsigned rb_magic;
 };
 
 #define RT_PIN() __builtin_amdgcn_sched_barrier(0)
 
+// VL3 (nout <= 4: the Gaussian actor's 4 moments, the critic's value): layer 3 on the VECTOR ALU from the same registers -- a lane
+// multiplies its 16 features of a chunk with their nout weights (LDS table, one ds_read_b128 per feature) and the two lane halves'
+// partial sums meet through one permute per output: 64 fused multiply-adds per chunk instead of 16 matrix instructions of 64 cycles
+// whose 32 output rows hold nout <= 4 values (7 % of the kernel's matrix time at h = 400, 13 % at h = 200).  The stream then holds
+// no L3 blocks.
+template <bool VL3>
 __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, int N, int d_in, const MArgsR rest)
 {
     MArgsR a = rest;
@@ -1397,11 +1404,45 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
     const int half = lane >> 5;
     const int nc1 = a.nc1, nc2 = a.nc2, ks1 = (a.d_in + 1) >> 1;
     float *sb2 = reinterpret_cast<float *>(smem);                  // b2, zero padded to whole chunks
-    char *ring = smem + ((nc2 * 32 * 4 + 15) & ~15) + wave * (kRtRing * 4096);
+    f32x4 *sw3 = reinterpret_cast<f32x4 *>(smem + nc2 * 32 * 4);   // VL3: W3[f][0..3] (zero beyond h2 / nout)
+    char *ring = smem + nc2 * 32 * 4 * (VL3 ? 5 : 1) + wave * (kRtRing * 4096);
 
+    // ---- the weight stream.  Everything about it is scalar except the lane's 16-byte slot: the float32 matrix instructions run
+    // on the vector ALUs, so every vector instruction in the loop is matrix time lost -- the DMA requests are issued by name with a
+    // scalar base and a constant 32-bit lane offset (hipcc forms 64-bit per-lane addresses with two v_lshl_add_u64 per request), and
+    // the ring reads by name with counted waits (hipcc waits for ALL outstanding LDS reads in front of a block's first instruction).
+    const unsigned long long sbase0 = reinterpret_cast<unsigned long long>(a.ws) + (unsigned long long)agent * a.blocks * 4096ull;
+    const unsigned voff = (unsigned)lane * 16u;                    // this lane's slot of a 1-KiB piece (global and LDS alike)
+    const unsigned ring_a = lds_addr(ring);
+    const unsigned rd_a = ring_a + voff;                           // LDS address of this lane's slot in ring block 0, piece 0
+    int cur = 0;                                                   // block being consumed; its ring slot = cur & 3
+    auto dma = [&](int blk, int q) {                               // piece q of stream block blk -> its ring slot
+        const unsigned long long src = sbase0 + (unsigned long long)(unsigned)blk * 4096ull + (unsigned)q * 1024u;
+        const unsigned dst = ring_a + (unsigned)(blk & (kRtRing - 1)) * 4096u + (unsigned)q * 1024u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+    };
+    f32x4 w[4];                                                    // the current block's sixteen A operands
+    // the ring is primed FIRST, ahead of the prologue's own loads: the first four blocks travel while b2 / x / W3 are fetched and
+    // the workgroup meets at its barrier (one global round trip less at the head of every wave: 5-10 % of a wave's life at h = 200)
+    if (e0 < a.E) {
+#pragma unroll 1
+        for (int b = 0; b < kRtRing; ++b) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma(b, q);
+        }
+    }
     for (int i = tid; i < nc2 * 32; i += 256) {                    // (clamped address, masked value: no branch around the load)
         const float v = a.b2[(size_t)agent * a.h2 + min(i, a.h2 - 1)];
         sb2[i] = __uint_as_float(__float_as_uint(v) & (i < a.h2 ? 0xffffffffu : 0u));
+        if (VL3) {
+            f32x4 wv;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float t = a.w3[((size_t)agent * a.h2 + min(i, a.h2 - 1)) * a.nout + min(o, a.nout - 1)];
+                wv[o] = __uint_as_float(__float_as_uint(t) & ((i < a.h2 && o < a.nout) ? 0xffffffffu : 0u));
+            }
+            sw3[i] = wv;
+        }
     }
     // the x operand of layer 1: k-step r = inputs 2 r + half of row (lane & 31)
     float xb[7];
@@ -1434,29 +1475,10 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
     }
     __syncthreads();                                               // b2 is in LDS; the only barrier of the kernel
     if (e0 >= a.E) return;                                         // a wave without rows (ragged last workgroup)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every load above has landed: from here vmcnt counts DMA pieces only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // every load above AND the ring's first four blocks have landed:
+                                                                   // from here vmcnt counts the DMA pieces requested in the loop only
 
-    // ---- the weight stream.  Everything about it is scalar except the lane's 16-byte slot: the float32 matrix instructions run
-    // on the vector ALUs, so every vector instruction in the loop is matrix time lost -- the DMA requests are issued by name with a
-    // scalar base and a constant 32-bit lane offset (hipcc forms 64-bit per-lane addresses with two v_lshl_add_u64 per request), and
-    // the ring reads by name with counted waits (hipcc waits for ALL outstanding LDS reads in front of a block's first instruction).
-    const unsigned long long sbase0 = reinterpret_cast<unsigned long long>(a.ws) + (unsigned long long)agent * a.blocks * 4096ull;
-    const unsigned voff = (unsigned)lane * 16u;                    // this lane's slot of a 1-KiB piece (global and LDS alike)
-    const unsigned ring_a = lds_addr(ring);
-    const unsigned rd_a = ring_a + voff;                           // LDS address of this lane's slot in ring block 0, piece 0
-    int cur = 0;                                                   // block being consumed; its ring slot = cur & 3
-    auto dma = [&](int blk, int q) {                               // piece q of stream block blk -> its ring slot
-        const unsigned long long src = sbase0 + (unsigned long long)(unsigned)blk * 4096ull + (unsigned)q * 1024u;
-        const unsigned dst = ring_a + (unsigned)(blk & (kRtRing - 1)) * 4096u + (unsigned)q * 1024u;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
-    };
-    f32x4 w[4];                                                    // the current block's sixteen A operands
-#pragma unroll 1
-    for (int b = 0; b < kRtRing; ++b) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dma(b, q);
-    }
-    asm volatile("s_waitcnt vmcnt(12)\n\tds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
+    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:2048\n\t"
                  "ds_read_b128 %3, %4 offset:3072" : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]) : "v"(rd_a) : "memory");
     // one group = the four matrix instructions of piece q (`mf`) -- the piece was requested from LDS a block ago: at most three
     // younger reads may still be out -- then the piece's ring slot is refilled with block cur + 4, and piece q of block cur + 1
@@ -1536,9 +1558,22 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
         // layer 3 from the finished chunks of this pass: two accumulation chains (even / odd chunks) that are added at the end --
         // half the roundings in a row on the outputs' own scale (every instruction rounds once; the 16-column instruction of the
         // LDS-staged kernel takes four products per rounding, this one two)
-        auto layer3 = [&](f32x16 &yy, f32x16 &h, int kv3) __attribute__((always_inline)) {
+        auto layer3 = [&](f32x16 &yy, f32x16 &h, int kv3, int c2) __attribute__((always_inline)) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[r] = fmaxf(h[r], 0.0f);
+            if constexpr (VL3) {                             // registers 0..3 of yy = this lane's partial sums of the nout <= 4 outputs
+                const f32x4 *wp = sw3 + 32 * c2 + 4 * half;  // this lane's features: 8 q + 4 half + j
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 wv = wp[8 * q + j];
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) yy[o] = fmaf(wv[o], h[4 * q + j], yy[o]);
+                    }
+                }
+                return;
+            }
             group(Q0{}, [&](const f32x4 &v) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) yy = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], h[j], yy, 0, 0, 0);
@@ -1567,7 +1602,7 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
         for (int i = 0; i < kRtChunks; ++i) {
             if (i < npc) {
                 const int kv3 = a.h2 - 32 * (c2_0 + i);      // features of this chunk (the same skipping as in layer 2)
-                if (i & 1) layer3(y1, acc2[i], kv3); else layer3(y, acc2[i], kv3);
+                if (i & 1) layer3(y1, acc2[i], kv3, c2_0 + i); else layer3(y, acc2[i], kv3, c2_0 + i);
             }
         }
     }
@@ -1575,8 +1610,17 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
 
     // ---- output activation + sampling: the wave's 32 x nout tile through its own LDS region, four lanes per env row
     float *st = reinterpret_cast<float *>(ring);                   // [32 rows][33]
+    if constexpr (VL3) {                                           // the two lane halves of a row hold the two halves of its features
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const float p = y[o] + y1[o];
+            const float other = __shfl_xor(p, 32, 64);
+            if (half == 0) st[(lane & 31) * 33 + o] = p + other;
+        }
+    } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[(lane & 31) * 33 + cd_row(r, lane)] = y[r] + y1[r];
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1765,11 +1809,12 @@ int mlp_forward_split(const char *what, const DroneMlpBf16 *m, const float *x, f
 }
 
 // blocks (4 KiB each) of one agent's row-tile weight stream, zero padding included (DroneMlp.w2_layout = 2; see mlp3_rt_kernel)
-extern "C" int dronesim_mlp_rt_blocks(int h1, int h2)
+// (nout <= 4: layer 3 runs on the vector ALU from the plain w3 array and the stream holds no L3 blocks)
+extern "C" int dronesim_mlp_rt_blocks(int h1, int h2, int nout)
 {
-    if (h1 < 1 || h2 < 1) return 0;
+    if (h1 < 1 || h2 < 1 || nout < 1) return 0;
     const int nc1 = (h1 + 31) / 32, nc2 = (h2 + 31) / 32;
-    return rt_passes(nc2) * nc1 + nc1 * nc2 + nc2 + kRtPad;
+    return rt_passes(nc2) * nc1 + nc1 * nc2 + (nout <= 4 ? 0 : nc2) + kRtPad;
 }
 
 extern "C" int dronesim_mlp_forward_bf16x3(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
@@ -1796,7 +1841,8 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
     if (m->w2_layout == 2) {
         // the row-tile stream (round 6): w2 = [N][dronesim_mlp_rt_blocks(h1, h2)][4][64][4] float32 holding W1, b1, W2 and W3 in the
         // kernel's consumption order; w1 / b1 / w3 are not read
-        if (!m->w2 || !m->b2 || !m->b3) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
+        const bool vl3 = m->nout <= 4;                            // layer 3 on the vector ALU, from the plain w3 array
+        if (!m->w2 || !m->b2 || !m->b3 || (vl3 && !m->w3)) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: NULL weight array");
         if (m->d_in > 14) return dronesim_fail(DRONESIM_EUNSUPPORTED, "dronesim_mlp_forward: w2_layout = 2 needs d_in <= 14");
         if ((reinterpret_cast<uintptr_t>(m->w2) & 15u) != 0)
             return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward: the row-tile stream (w2_layout = 2) must be 16-byte aligned");
@@ -1804,20 +1850,22 @@ extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *ou
         MArgsR r{};
         r.E = E; r.N = m->N; r.d_in = m->d_in; r.h1 = m->h1; r.h2 = m->h2; r.nout = m->nout;
         r.nc1 = (m->h1 + 31) / 32; r.nc2 = (m->h2 + 31) / 32;
-        r.blocks = dronesim_mlp_rt_blocks(m->h1, m->h2);
-        r.x = x; r.ws = m->w2; r.b2 = m->b2; r.b3 = m->b3;
+        r.blocks = dronesim_mlp_rt_blocks(m->h1, m->h2, m->nout);
+        r.x = x; r.ws = m->w2; r.b2 = m->b2; r.b3 = m->b3; r.w3 = m->w3;
         r.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
-        const size_t lds = (((size_t)r.nc2 * 32 * 4 + 15) & ~(size_t)15) + 4 * (size_t)kRtRing * 4096;
+        const size_t lds = (size_t)r.nc2 * 32 * 4 * (vl3 ? 5 : 1) + 4 * (size_t)kRtRing * 4096;
         {
             static std::mutex mu;
-            static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
-            const int lrc = enable_big_lds(reinterpret_cast<const void *>(mlp3_rt_kernel), opted, mu, "mlp3_rt_kernel");
+            static unsigned long long opted[2][4] = {};
+            const int lrc = enable_big_lds(vl3 ? reinterpret_cast<const void *>(mlp3_rt_kernel<true>) : reinterpret_cast<const void *>(mlp3_rt_kernel<false>),
+                                           opted[vl3 ? 1 : 0], mu, "mlp3_rt_kernel");
             if (lrc) return lrc;
         }
         const unsigned rb = (unsigned)((E + kRtRows - 1) / kRtRows);
         const dim3 grid(rb * m->N);
         r.rb_magic = div_magic(grid.x, rb);
-        hipLaunchKernelGGL(mlp3_rt_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), r.x, r.E, r.N, r.d_in, r);
+        if (vl3) hipLaunchKernelGGL(mlp3_rt_kernel<true>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), r.x, r.E, r.N, r.d_in, r);
+        else hipLaunchKernelGGL(mlp3_rt_kernel<false>, grid, dim3(256), lds, static_cast<hipStream_t>(stream), r.x, r.E, r.N, r.d_in, r);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
         return DRONESIM_OK;

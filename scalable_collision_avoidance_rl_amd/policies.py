@@ -189,7 +189,7 @@ def pack_f32_rowtile_stream(w1, b1, w2, w3):
     (`DroneMlp.w2_layout = 2`, csrc/policy.hip: mlp3_rt_kernel): ``[N, blocks, 4, 64, 4]`` float32, blocks of four 1-KiB pieces
     ``[64 lanes][4 floats]`` (lane = 32 half + i) in the kernel's consumption order:
 
-        per pass p (output chunks S_p):  for c1: L1(c1), L2(c1, c2) for c2 in S_p;  then L3(c2) for c2 in S_p;  RT_PAD zero blocks
+        per pass p (output chunks S_p):  for c1: L1(c1), L2(c1, c2) for c2 in S_p;  then (nout > 4 only) L3(c2) for c2 in S_p;  RT_PAD zero blocks
         L1(c1):      piece 0 = W1[2 r + half, 32 c1 + i] for r = 0..3;  piece 1 = the same for r = 4..6, then b1[32 c1 + i] (lanes < 32)
         L2(c1, c2):  piece q = W2[32 c1 + 8 q + 4 half + j, 32 c2 + i],  j = 0..3
         L3(c2):      piece q = W3[32 c2 + 8 q + 4 half + j, i]
@@ -224,7 +224,8 @@ def pack_f32_rowtile_stream(w1, b1, w2, w3):
         for c1 in range(nc1):
             seq.append(l1[:, c1])
             seq += [l2[:, c1, c2] for c2 in chunks]
-        seq += [l3[:, c2] for c2 in chunks]
+        if nout > 4:                                   # (nout <= 4: layer 3 runs on the vector ALU from the plain w3 array)
+            seq += [l3[:, c2] for c2 in chunks]
     seq += [torch.zeros_like(l1[:, 0])] * RT_PAD
     return torch.stack(seq, dim=1).contiguous()
 
@@ -274,7 +275,7 @@ class BatchedMLP:
         elif precision == "f32" and pack_w2 and self.d_in <= 14:
             # round 6: ONE stream holding all three layers in the row-tile kernel's consumption order (`DroneMlp.w2_layout = 2`)
             self._w2p = pack_f32_rowtile_stream(self.w1, self.b1, self.w2, self.w3)
-            assert self._w2p.shape[1] == int(self._lib.dronesim_mlp_rt_blocks(self.h1, self.h2))
+            assert self._w2p.shape[1] == int(self._lib.dronesim_mlp_rt_blocks(self.h1, self.h2, self.nout))
             m.w2, m.w2_layout = self._w2p.data_ptr(), 2
             self._rowtile = True
         elif precision == "f32" and pack_w2:

@@ -223,7 +223,7 @@ def test_pack_f32_rowtile_stream_layout():
         nc1, nc2 = (h1 + 31) // 32, (h2 + 31) // 32
         passes = (nc2 + P.RT_CHUNKS - 1) // P.RT_CHUNKS
         per = (nc2 + passes - 1) // passes
-        assert st.shape == (n, int(lib.dronesim_mlp_rt_blocks(h1, h2)), 4, 64, 4) and st.dtype == torch.float32 and st.is_contiguous()
+        assert st.shape == (n, int(lib.dronesim_mlp_rt_blocks(h1, h2, no)), 4, 64, 4) and st.dtype == torch.float32 and st.is_contiguous()
         el = lambda t, a, k, c: float(t[a, k, c]) if k < t.shape[1] and c < t.shape[2] else 0.0
         rng = np.random.default_rng(1)
         blk = 0
@@ -243,7 +243,7 @@ def test_pack_f32_rowtile_stream_layout():
                     for _ in range(12):
                         a, lane, q, j = (int(rng.integers(0, m)) for m in (n, 64, 4, 4))
                         assert float(B[a, q, lane, j]) == el(w2, a, 32 * c1 + 8 * q + 4 * (lane >> 5) + j, 32 * c2 + (lane & 31))
-            for c2 in chunks:
+            for c2 in (chunks if no > 4 else ()):                  # (nout <= 4: no L3 blocks, layer 3 reads the plain w3 array)
                 B = st[:, blk]; blk += 1
                 for _ in range(12):
                     a, lane, q, j = (int(rng.integers(0, m)) for m in (n, 64, 4, 4))
