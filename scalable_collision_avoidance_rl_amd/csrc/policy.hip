@@ -13,6 +13,9 @@
 //
 // Arithmetic: exact float32 on the matrix cores -- v_mfma_f32_32x32x2_f32 is a k-ordered fmaf chain
 // (no reduced precision), so results match a float32 torch reference to round-off.
+// Since round 6 the host class hands the weights over as ONE packed stream per agent (DroneMlp.w2_layout = 2) and the kernel is
+// mlp3_rt_kernel further down: a wave owns 32 env rows and every output chunk, the layers meet in registers.  The kernel described
+// here (mlp3_kernel: w2_layout = 0 / 1, activations staged through LDS) is the one of rounds 2-5.
 // Decomposition: ceil(E/32) x N workgroups (XCD-aware order, see xcd_work_item): one workgroup = 32 env rows of ONE agent, 4 waves.
 //   wave w owns every fourth 32-column chunk of the hidden layers (one 32x32 accumulator tile).
 //   32 rows keep the workgroup at ~57 KiB of LDS, so two workgroups share a CU and one's prologue, barriers
