@@ -29,7 +29,7 @@ STATS_SCRATCH_DOUBLES = 769          # DRONESIM_STATS_SCRATCH_DOUBLES (include/d
 EPISODE_REDUCE_DOUBLES = 8           # DRONESIM_EPISODE_REDUCE_DOUBLES
 SYMBOLS = ("dronesim_step", "dronesim_observe", "dronesim_reset", "dronesim_rollout", "dronesim_control", "dronesim_returns", "dronesim_advantage", "dronesim_episode_stats", "dronesim_mlp_forward", "dronesim_mlp_forward_bf16",
            "dronesim_step_ex", "dronesim_step_call", "dronesim_rollout_ex", "dronesim_rollout_random", "dronesim_reset_ex", "dronesim_reset_observe", "dronesim_episode_reduce",
-           "dronesim_mlp_forward_bf16x3", "dronesim_mlp_forward_f16x2", "dronesim_mlp_bf16x3_stages", "dronesim_mlp_rt_blocks",
+           "dronesim_mlp_forward_bf16x3", "dronesim_mlp_forward_f16x2", "dronesim_mlp_bf16x3_stages", "dronesim_mlp_rt_blocks", "dronesim_mlp_rt16_blocks", "dronesim_mlp_forward_f16x2_rt",
            "dronesim_last_error", "dronesim_error_string", "dronesim_version")
 
 
@@ -136,6 +136,9 @@ def lib():
     L.dronesim_mlp_forward_f16x2.restype = C.c_int
     L.dronesim_mlp_bf16x3_stages.argtypes = [C.c_int, C.c_int]
     L.dronesim_mlp_rt_blocks.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.dronesim_mlp_rt16_blocks.argtypes = [C.c_int, C.c_int]
+    L.dronesim_mlp_forward_f16x2_rt.argtypes = L.dronesim_mlp_forward_bf16.argtypes
+    L.dronesim_mlp_forward_f16x2_rt.restype = C.c_int
     L.dronesim_mlp_bf16x3_stages.restype = C.c_int
     L.dronesim_reset.argtypes = [P, i32, i32, f32, u64, i64] + [vp] * 6 + [i32, vp]
     PC = C.POINTER(DroneEpisodeCtl)

@@ -1644,6 +1644,251 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
 }
 #undef RT_PIN
 
+// ---------------------------------------------------------------------------------------------------------
+// Two-part float16 split (f16x2), ROW-TILE ownership with ONE weight ring per workgroup (round 6; dronesim_mlp_forward_f16x2_rt).
+// The formulation of mlp3_rt_kernel on v_mfma_f32_32x32x16_f16: a wave owns 32 env rows of one agent and every output chunk of layer 2
+// for them (kRtChunks accumulator tiles per pass, layer 1 recomputed in the second pass), layers meet in registers through the
+// float16 split of the accumulator tile, layer 3 (nout <= 4) runs on the vector ALU in exact float32.  Against mlp3_split_kernel
+// (wave w owns output chunks w, w + 4, ... of two row tiles): no layer-1 work and no relu + split repeated by four waves, no
+// 4-3-3-3 dealing of 13 chunks -- 1053 instead of 1500 matrix instructions per 32 rows at h = 400 -- and HALF the weight bytes per
+// matrix instruction, because the four waves of a workgroup consume the SAME stream: it travels global -> LDS once per workgroup,
+// into a ring of kR16Depth super-stages of four 4-KiB blocks; wave w requests piece w of every block.  One s_barrier per super-stage
+// (24 matrix instructions) orders it: a wave that is about to read the first block of super-stage S has waited for its own pieces of
+// S (counted vmcnt) and holds all of S - 1 in registers, so behind the barrier S is complete in LDS and the slot of S - 1 is free
+// for super-stage S + 2.  No other barrier after the prologue.
+// One agent's stream (blocks of four 1-KiB pieces [64 lanes][8 float16]; policies.py: pack_f16_rowtile_stream):
+//   per pass p (output chunks S_p):  for c1:  L1(c1) = (W1 hi, W1 lo, 0, 0) of chunk c1 (one 16-wide k-step, linear k order),
+//                                             L2(c1, c2) = (hi, lo of k-step 2 c1), (hi, lo of k-step 2 c1 + 1) for c2 in S_p
+//                                             (accumulator k order: 16 s + 8 (j >> 2) + 4 half + (j & 3));
+//   padded to whole super-stages, then two empty super-stages.  Weights carry DroneMlpBf16.wscale like the split kernel's.
+constexpr int kR16Depth = 3;
+
+struct MArgsR16 {
+    int E, N, d_in, h1, h2, nout, nc1, nc2, blocks;
+    const float *x, *b1, *b2, *b3, *w3, *wscale;
+    const char *ws;
+    FinishArgs fin;
+    unsigned rb_magic;
+};
+
+__global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E, int N, int d_in, const MArgsR16 rest)
+{
+    typedef SchemeF16x2 S;
+    constexpr int P = 2;
+    MArgsR16 a = rest;
+    a.x = x; a.E = E; a.N = N; a.d_in = d_in;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int agent, row_block;
+    xcd_work_item((a.E + kRtRows - 1) / kRtRows, agent, row_block, a.rb_magic);
+    const int e0 = row_block * kRtRows + 32 * wave;                // this wave's 32 env rows (a wave without rows runs on clamped ones:
+    const int half = lane >> 5;                                    // every wave takes part in every barrier)
+    const int nc1 = a.nc1, nc2 = a.nc2;
+    float ws1 = 1.0f, ws2 = 1.0f, wi1 = 1.0f, wi2 = 1.0f;
+    if (a.wscale != nullptr) {
+        ws1 = a.wscale[3 * (size_t)agent]; ws2 = a.wscale[3 * (size_t)agent + 1];
+        wi1 = __builtin_amdgcn_rcpf(ws1); wi2 = __builtin_amdgcn_rcpf(ws2);
+    }
+    float *sb1 = reinterpret_cast<float *>(smem);                  // b1 * ws1 | b2 * ws2, zero padded to whole chunks
+    float *sb2 = sb1 + nc1 * 32;
+    f32x4 *sw3 = reinterpret_cast<f32x4 *>(sb2 + nc2 * 32);        // W3[f][0..3] (float32, unscaled; zero beyond h2 / nout)
+    char *ring = reinterpret_cast<char *>(sw3 + nc2 * 32);         // [kR16Depth][4 blocks][4 pieces][1 KiB], shared by the workgroup
+
+    // ---- the weight stream: wave w requests piece w of every block (scalar base + this lane's 16-byte slot, by name)
+    const unsigned long long sbase0 = reinterpret_cast<unsigned long long>(a.ws) + (unsigned long long)agent * a.blocks * 4096ull +
+                                      (unsigned long long)wave * 1024ull;
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned ring_a = lds_addr(ring);
+    const unsigned rd_a = ring_a + voff;
+    auto dma_super = [&](int sst) {                                // this wave's four pieces of super-stage sst
+        const unsigned slot = ring_a + (unsigned)(sst % kR16Depth) * 16384u + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned long long src = sbase0 + (unsigned long long)(unsigned)(4 * sst + b) * 4096ull;
+            const unsigned dst = slot + (unsigned)b * 4096u;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
+        }
+    };
+#pragma unroll 1
+    for (int sst = 0; sst < kR16Depth; ++sst) dma_super(sst);      // primed ahead of the prologue's own loads
+
+    for (int i = tid; i < (nc1 + nc2) * 32; i += 256) {            // (clamped address, masked value: no branch around the loads)
+        const bool l1 = i < nc1 * 32;
+        const int j = l1 ? i : i - nc1 * 32, h = l1 ? a.h1 : a.h2;
+        const float v = (l1 ? a.b1 : a.b2)[(size_t)agent * h + min(j, h - 1)];
+        sb1[i] = __uint_as_float(__float_as_uint(v) & (j < h ? 0xffffffffu : 0u)) * (l1 ? ws1 : ws2);
+        if (!l1) {
+            f32x4 wv;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float t = a.w3[((size_t)agent * a.h2 + min(j, a.h2 - 1)) * a.nout + min(o, a.nout - 1)];
+                wv[o] = __uint_as_float(__float_as_uint(t) & ((j < a.h2 && o < a.nout) ? 0xffffffffu : 0u));
+            }
+            sw3[j] = wv;
+        }
+    }
+    // the x operand of layer 1 (one 16-wide k-step, linear order: inputs 8 half + j of row lane & 31), split once
+    Parts<P> xB;
+    {
+        const int e = min(e0 + (lane & 31), a.E - 1);
+        const float *xr = a.x + ((size_t)e * a.N + agent) * a.d_in;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * half + j;
+            const float xv = xr[min(k, a.d_in - 1)];
+            v[j] = __uint_as_float(__float_as_uint(xv) & (k < a.d_in ? 0xffffffffu : 0u));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned d[P];
+            S::template split_pair<false>(v[2 * q], v[2 * q + 1], d);
+#pragma unroll
+            for (int p = 0; p < P; ++p) xB.p[p][q] = d[p];
+        }
+    }
+    uint32_t tval[2] = {0u, 0u}, epval[2] = {0u, 0u};
+    float b3v[2][kQ];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = e0 + 16 * it + (lane >> 2);
+        if (e < a.E && a.fin.sample_kind != 0) {
+            if (a.fin.t_dev) tval[it] = (uint32_t)a.fin.t_dev[e];
+            if (a.fin.episode_dev) epval[it] = (uint32_t)a.fin.episode_dev[e];
+        }
+#pragma unroll
+        for (int i = 0; i < kQ; ++i) {
+            const int j = (lane & 3) + 4 * i;
+            const float v = a.b3[(size_t)agent * a.nout + min(j, a.nout - 1)];
+            b3v[it][i] = j < a.nout ? v : 0.0f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's loads and its pieces of the first three super-stages
+    __syncthreads();                                               // ... and everybody else's: biases, W3 and the ring are in LDS
+
+    // ---- consumption.  wf[0..3] = the current block's pieces (k-step 0 hi, lo; k-step 1 hi, lo); a piece is re-read with the NEXT
+    // block's bytes right behind its last product.  `cur` = index of the block whose pieces are being (re)loaded.
+    u32x4 wf[4];
+    int cur = 0;
+    // (requested in the order the pieces are consumed -- lo, hi of k-step 0, then lo, hi of k-step 1 -- so that the piece about to
+    // be used is always the OLDEST of at most four reads in flight: every wait below is lgkmcnt(3))
+    asm volatile("ds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %0, %4\n\tds_read_b128 %3, %4 offset:3072\n\tds_read_b128 %2, %4 offset:2048"
+                 : "=&v"(wf[0]), "=&v"(wf[1]), "=&v"(wf[2]), "=&v"(wf[3]) : "v"(rd_a) : "memory");
+    // the first read of a block: when it opens super-stage sst >= 1, the workgroup meets first (see the header)
+    auto open_block = [&]() {
+        ++cur;
+        if ((cur & 3) == 0) {
+            const int sst = cur >> 2;
+            // this wave's pieces of sst have landed (sst + 1's four may be out), and its reads of sst - 1's last block are complete
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_super(sst + kR16Depth - 1);                        // the slot of sst - 1: every wave holds its last block in registers
+        }
+    };
+    // (immediate offsets per piece: four variants by name)
+    auto ring_read_p = [&](u32x4 &dst, auto PIECE) {
+        constexpr int piece = decltype(PIECE)::value;
+        const unsigned ra = rd_a + (unsigned)((cur >> 2) % kR16Depth) * 16384u + (unsigned)(cur & 3) * 4096u;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ra), "n"(piece * 1024) : "memory");
+    };
+    typedef std::integral_constant<int, 0> P0; typedef std::integral_constant<int, 1> P1;
+    typedef std::integral_constant<int, 2> P2; typedef std::integral_constant<int, 3> P3;
+    // one k-step of a block: the scheme's three products (lo.hi, hi.lo, hi.hi) of pieces (hiP, loP) with the B parts `b`; each piece is
+    // reloaded with the next block's bytes behind its last product; FIRST: this k-step opens the next block (k-step 0)
+    // `live` (wave-uniform): false = the k-step holds no feature (ragged last chunk): its pieces only make way for the next block's.
+    // NOTE the reads are UNCONDITIONAL and only the matrix instructions sit under the branch: a register that an asynchronous read
+    // issued by name is still filling must never meet a control-flow join -- hipcc resolves the join with register copies and does
+    // not know that the value is not there yet (the first cut of this kernel copied stale pieces that way).
+    auto kstep = [&](f32x16 &acc, const Parts<P> &b, auto HI, auto LO, auto FIRST, bool live) {
+        constexpr int hi = decltype(HI)::value, lo = decltype(LO)::value;
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[lo]) :: "memory");
+        if (live) acc = S::mfma(wf[lo], b.p[0], acc);              // lo . hi
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(FIRST)::value) open_block();
+        ring_read_p(wf[lo], LO);
+        asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(wf[hi]) :: "memory");
+        if (live) {
+            acc = S::mfma(wf[hi], b.p[1], acc);                    // hi . lo
+            acc = S::mfma(wf[hi], b.p[0], acc);                    // hi . hi
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ring_read_p(wf[hi], HI);
+    };
+
+    f32x4 ya = {0.0f, 0.0f, 0.0f, 0.0f}, yb = ya;                  // layer 3 (vector ALU): this lane's partial sums of the outputs
+    const int passes = rt_passes(nc2), per = rt_per_pass(nc2);
+    for (int p = 0; p < passes; ++p) {
+        const int c2_0 = p * per, npc = min(per, nc2 - c2_0);
+        f32x16 acc2[kRtChunks];
+#pragma unroll
+        for (int i = 0; i < kRtChunks; ++i) acc2[i] = bias_tile(sb2 + min(c2_0 + i, nc2 - 1) * 32, lane);
+        for (int c1 = 0; c1 < nc1; ++c1) {
+            // layer 1 of chunk c1 (block L1: pieces 0, 1 = W1 hi, lo; 2, 3 unused), then relu + split -> the two k-steps' B operands
+            f32x16 a1 = bias_tile(sb1 + c1 * 32, lane);
+            kstep(a1, xB, P0{}, P1{}, std::true_type{}, true);
+            kstep(a1, xB, P2{}, P3{}, std::false_type{}, false);
+            Parts<P> hB0, hB1;
+            { SplitJob<S, 0, 1> j(a1, hB0, wi1); j.all(); }
+            { SplitJob<S, 1, 1> j(a1, hB1, wi1); j.all(); }
+            const int kv = a.h1 - 32 * c1;                         // features of this in-chunk: a ragged last chunk of <= 16 has no second k-step
+#pragma unroll
+            for (int i = 0; i < kRtChunks; ++i) {
+                if (i < npc) {
+                    kstep(acc2[i], hB0, P0{}, P1{}, std::true_type{}, true);
+                    kstep(acc2[i], hB1, P2{}, P3{}, std::false_type{}, kv > 16);
+                }
+            }
+        }
+        // layer 3 on the vector ALU, exact float32: relu, undo layer 2's weight factor, 16 features x nout <= 4 per chunk
+#pragma unroll
+        for (int i = 0; i < kRtChunks; ++i) {
+            if (i < npc) {
+                const f32x4 *wp = sw3 + 32 * (c2_0 + i) + 4 * half;
+                f32x4 part = {0.0f, 0.0f, 0.0f, 0.0f};           // this chunk's contribution (two chains: even / odd chunks)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float hv = fmaxf(acc2[i][4 * q + j], 0.0f) * wi2;
+                        const f32x4 wv = wp[8 * q + j];
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) part[o] = fmaf(wv[o], hv, part[o]);
+                    }
+                }
+                if (i & 1) yb += part; else ya += part;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // no DMA may land late: the output tile reuses the ring
+    __syncthreads();                                               // ... and no wave may still be reading it
+
+    float *st = reinterpret_cast<float *>(ring) + wave * (32 * 33);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const float pv = ya[o] + yb[o];
+        const float other = __shfl_xor(pv, 32, 64);
+        if (half == 0) st[(lane & 31) * 33 + o] = pv + other;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = 16 * it + (lane >> 2), part = lane & 3;
+        const int e = e0 + row;
+        if (e < a.E) {
+            float yv[kQ];
+#pragma unroll
+            for (int i = 0; i < kQ; ++i) {
+                const int j = part + 4 * i;
+                yv[i] = j < a.nout ? st[row * 33 + j] + b3v[it][i] : 0.0f;
+            }
+            finish_quad(a.fin, yv, e, agent, part, tval[it], epval[it]);
+        }
+    }
+}
+
 // > 64 KiB of dynamic LDS must be opted into once per (kernel, device): a bit mask of device ordinals per kernel,
 // guarded by a mutex (the library may be driven from several host threads / devices of one process)
 int enable_big_lds(const void *kernel, unsigned long long (&opted)[4], std::mutex &mu, const char *what)
@@ -1832,6 +2077,54 @@ extern "C" int dronesim_mlp_forward_f16x2(const DroneMlpBf16 *m, const float *x,
                                           const int32_t *t, const int32_t *episode, int E, void *stream)
 {
     return mlp_forward_split<SchemeF16x2>("f16x2", m, x, out, act, act_idx, seed, counter, env_base, t, episode, E, stream);
+}
+
+// blocks (4 KiB) of one agent's float16 row-tile stream (dronesim_mlp_forward_f16x2_rt): the real blocks rounded up to whole
+// super-stages of four, plus three super-stages of padding for the run-ahead of the DMA requests
+extern "C" int dronesim_mlp_rt16_blocks(int h1, int h2)
+{
+    if (h1 < 1 || h2 < 1) return 0;
+    const int nc1 = (h1 + 31) / 32, nc2 = (h2 + 31) / 32;
+    const int real = rt_passes(nc2) * nc1 + nc1 * nc2;
+    return ((real + 3) / 4 + 3) * 4;
+}
+
+extern "C" int dronesim_mlp_forward_f16x2_rt(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
+                                             uint64_t seed, uint64_t counter, int64_t env_base,
+                                             const int32_t *t, const int32_t *episode, int E, void *stream)
+{
+    if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: NULL argument");
+    const int rc = check_mlp("f16x2_rt", m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
+    if (rc) return rc;
+    if (m->d_in > 16 || m->nout > 4) return dronesim_fail(DRONESIM_EUNSUPPORTED, "dronesim_mlp_forward_f16x2_rt: d_in <= 16 and nout <= 4");
+    if (!m->w1p || !m->w3p || !m->b1 || !m->b2 || !m->b3)
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: NULL weight array");
+    if (m->reserved != dronesim_mlp_rt16_blocks(m->h1, m->h2))
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: DroneMlpBf16.reserved must hold dronesim_mlp_rt16_blocks(h1, h2)");
+    if ((reinterpret_cast<uintptr_t>(m->w1p) & 15u) != 0)
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: the stream must be 16-byte aligned");
+    if (E == 0) return DRONESIM_OK;
+    MArgsR16 r{};
+    r.E = E; r.N = m->N; r.d_in = m->d_in; r.h1 = m->h1; r.h2 = m->h2; r.nout = m->nout;
+    r.nc1 = (m->h1 + 31) / 32; r.nc2 = (m->h2 + 31) / 32;
+    r.blocks = m->reserved;
+    r.x = x; r.b1 = m->b1; r.b2 = m->b2; r.b3 = m->b3; r.w3 = reinterpret_cast<const float *>(m->w3p); r.wscale = m->wscale;
+    r.ws = reinterpret_cast<const char *>(m->w1p);
+    r.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
+    const size_t lds = (size_t)(r.nc1 + r.nc2) * 32 * 4 + (size_t)r.nc2 * 32 * 16 + (size_t)kR16Depth * 16384;
+    {
+        static std::mutex mu;
+        static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
+        const int lrc = enable_big_lds(reinterpret_cast<const void *>(mlp3_rt16_kernel), opted, mu, "mlp3_rt16_kernel");
+        if (lrc) return lrc;
+    }
+    const unsigned rb = (unsigned)((E + kRtRows - 1) / kRtRows);
+    const dim3 grid(rb * m->N);
+    r.rb_magic = div_magic(grid.x, rb);
+    hipLaunchKernelGGL(mlp3_rt16_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), r.x, r.E, r.N, r.d_in, r);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
+    return DRONESIM_OK;
 }
 
 extern "C" int dronesim_mlp_forward(const DroneMlp *m, const float *x, float *out, float *act, int32_t *act_idx,

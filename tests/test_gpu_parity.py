@@ -34,6 +34,12 @@ def env_for(fx, E):
     return env
 
 
+def _prec_kw(prec):
+    """BatchedMLP keywords of a test's precision label: "f16x2" with nout <= 4 runs the row-tile float16 kernel of round 6
+    (mlp3_rt16_kernel), "f16x2-split" keeps it on the split kernel of rounds 2-5 (which every other nout still takes)."""
+    return dict(precision="f16x2", split_kernel=True) if prec == "f16x2-split" else dict(precision=prec)
+
+
 def host(t):
     return t.detach().cpu().numpy()
 
@@ -304,7 +310,7 @@ def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch, prec):
         m.input_layer, m.hidden_layer1, m.hidden_layer2 = lin(6, 400, 0.08), lin(400, 200, 0.08), lin(400, 200, 0.08)
         m.out_1, m.out_2 = lin(200, 2, 0.15), lin(200, 2, 0.15)
         mods.append(m)
-    pol = BatchedMLP.from_normal_actor(mods, seed=9, precision=prec)
+    pol = BatchedMLP.from_normal_actor(mods, seed=9, **_prec_kw(prec))
     assert (pol.h1, pol.h2, pol.nout) == (400, 400, 4)
     W = lambda name: torch.stack([getattr(m, name).weight.double() for m in mods])          # [N, out, in]
     B = lambda name: torch.stack([getattr(m, name).bias.double() for m in mods])
@@ -344,7 +350,7 @@ def test_c5_gaussian_policy_in_the_loop_at_full_shard_size(torch, prec):
     assert abs((eps ** 4).mean() - 3.0) < 0.08                                    # Gaussian, not just unit variance
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16x2", "f16x2-split"])
 def test_c5_gaussian_policy_stress_weights_hold_the_bar(torch, prec):
     """The precisions the C5 line is quoted with (bench.py `other_workloads.c5_gaussian_*`) hold the 1e-5 bar on the
     C5 shard's OWN observation (|z| up to ~243 on the 256 grid) at the builder's stress weights -- the case of
@@ -369,7 +375,7 @@ def test_c5_gaussian_policy_stress_weights_hold_the_bar(torch, prec):
     y = torch.einsum("enk,nko->eno", h, W[4]) + W[5]
     ref = torch.cat([torch.tanh(y[..., :2]), torch.sigmoid(y[..., 2:])], -1).numpy()
     assert float(h.abs().max()) > 20.0                                    # hidden activations well beyond the init regime
-    pol = BatchedMLP(*w, out_kind=2, sample_kind=0, precision=prec)
+    pol = BatchedMLP(*w, out_kind=2, sample_kind=0, **_prec_kw(prec))
     out = host(pol.forward(z)).astype(np.float64)
     err = np.abs(out - ref) / (H.ATOL + H.RTOL * np.abs(ref))
     assert err.max() <= 1.0, f"{prec}: worst error {err.max():.3f} x the 1e-5 bar"
@@ -1017,7 +1023,7 @@ def test_batched_policy_large_batch_and_sampling_statistics(torch):
     H.assert_close(host(crit.forward(x.cuda())), ref(x, wc, lambda y: y), "critic 200x200x1")
 
 
-@pytest.mark.parametrize("prec", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("prec", ["bf16x3", "f16x2", "f16x2-split"])
 def test_batched_policy_split_precisions_hold_the_float32_bar(torch, prec):
     """precision="bf16x3" (three-part bf16 splits of weights and activations, six matrix instructions per product) and
     "f16x2" (two-part float16 splits, three per product): the SAME 1e-5 bar as the exact-float32 kernel: on the
@@ -1026,7 +1032,7 @@ def test_batched_policy_split_precisions_hold_the_float32_bar(torch, prec):
     from scalable_collision_avoidance_rl_amd.policies import BatchedMLP
     fx = H.load("policies.npz")
     x = torch.tensor(fx["x"], dtype=torch.float32, device="cuda:0")
-    kw = dict(precision=prec)
+    kw = _prec_kw(prec)
     soft = BatchedMLP.from_discrete_softmax(_modules(fx, "soft", ["input_layer", "hidden_layer1", "out_1"]), **kw)
     H.assert_close(host(soft.forward(x)), fx["soft_out"], f"softmax probs ({prec})")
     norm = BatchedMLP.from_normal_actor(_modules(fx, "norm", ["input_layer", "hidden_layer1", "hidden_layer2", "out_1", "out_2"]), **kw)
@@ -1052,7 +1058,7 @@ def test_batched_policy_split_precisions_hold_the_float32_bar(torch, prec):
             (20, 20, 1, 0, 0, lambda y: y),
             (512, 512, 32, 0, 0, lambda y: y)]:
         w = (r(N, d, h1) * 0.4, r(N, h1) * 0.4, r(N, h1, h2) * 0.08, r(N, h2) * 0.4, r(N, h2, nout) * 0.08, r(N, nout) * 0.4)
-        x3 = BatchedMLP(*w, out_kind=ok, sample_kind=sk, precision=prec, seed=3)
+        x3 = BatchedMLP(*w, out_kind=ok, sample_kind=sk, seed=3, **kw)
         f32 = BatchedMLP(*w, out_kind=ok, sample_kind=sk, precision="f32", seed=3)
         y3 = host(x3.forward(xr.cuda()))
         H.assert_close(y3, ref(xr, w, act), f"{prec} vs float64 {h1}x{h2}x{nout}")
@@ -1092,10 +1098,10 @@ def test_policy_shape_fuzz_all_precisions(torch):
                else torch.cat([torch.tanh(y[..., :2]), torch.sigmoid(y[..., 2:])], -1)).numpy()
         tag = f"policy fuzz#{it} d={d} h1={h1} h2={h2} nout={nout} kind={kind} N={N} E={E}"
         # ("f32" = the row-tile stream of round 6 for d_in <= 14, else the fragment-packed layer 2; the other two layouts by name)
-        for prec in ("f32", "f32-fragments", "f32-w2-unpacked", "bf16x3", "f16x2", "bf16"):
+        for prec in ("f32", "f32-fragments", "f32-w2-unpacked", "bf16x3", "f16x2", "f16x2-split", "bf16"):
             pol = (BatchedMLP(*w, out_kind=kind, sample_kind=0, precision="f32", pack_w2=False) if prec == "f32-w2-unpacked"
                    else BatchedMLP(*w, out_kind=kind, sample_kind=0, precision="f32", pack_w2="fragments") if prec == "f32-fragments"
-                   else BatchedMLP(*w, out_kind=kind, sample_kind=0, precision=prec))
+                   else BatchedMLP(*w, out_kind=kind, sample_kind=0, **_prec_kw(prec)))
             out = host(pol.forward(x.cuda()))
             if prec == "bf16":
                 H.assert_close(out, ref, f"{tag} {prec}", rtol=3e-2, atol=3e-2 * max(1.0, float(np.abs(ref).max())))
@@ -1612,7 +1618,7 @@ def test_episode_statistic_kernel(torch):
 
 
 # ------------------------------------------------------------------------------- round 4: ADVICE r3 items on the policies
-@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16x2", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x3", "f16x2", "f16x2-split", "bf16"])
 def test_policy_weight_updates_reach_the_kernel_after_refresh(torch, prec):
     """The kernels read PACKED images of the weights (snapshots).  After an in-place update of the live tensors the
     outputs are stale until `refresh_weights()` re-packs -- into the SAME device buffers (a captured graph stays valid) --
@@ -1622,7 +1628,7 @@ def test_policy_weight_updates_reach_the_kernel_after_refresh(torch, prec):
     g = torch.Generator().manual_seed(3)
     r = lambda *s: (torch.rand(*s, generator=g) * 2 - 1) * 0.3
     w = [r(N, d, h), r(N, h), r(N, h, h), r(N, h), r(N, h, nout), r(N, nout)]
-    pol = BatchedMLP(*w, 2, 0, device="cuda", precision=prec)                   # ("cuda" without an index is accepted)
+    pol = BatchedMLP(*w, 2, 0, device="cuda", **_prec_kw(prec))                  # ("cuda" without an index is accepted)
     x = torch.rand(E, N, d, device="cuda:0") * 2 - 1
     out0 = pol.forward(x).clone()
     ptrs = [getattr(pol, n).data_ptr() for n in ("_w1p", "_w2p", "_w3p") if getattr(pol, n, None) is not None]
@@ -1633,11 +1639,11 @@ def test_policy_weight_updates_reach_the_kernel_after_refresh(torch, prec):
     pol.refresh_weights()
     assert ptrs == [getattr(pol, n).data_ptr() for n in ("_w1p", "_w2p", "_w3p") if getattr(pol, n, None) is not None]
     out1 = pol.forward(x, out=graph_out)                                        # out= on device "cuda:0" with a "cuda" policy
-    ref = BatchedMLP(*w2, 2, 0, device="cuda:0", precision=prec).forward(x)
+    ref = BatchedMLP(*w2, 2, 0, device="cuda:0", **_prec_kw(prec)).forward(x)
     assert torch.equal(out1, ref) and not torch.equal(out1, out0)
     pol.refresh_weights(w2=w[2])                                                # the keyword form copies, then re-packs
     w3 = list(w2); w3[2] = w[2]
-    assert torch.equal(pol.forward(x), BatchedMLP(*w3, 2, 0, device="cuda:0", precision=prec).forward(x))
+    assert torch.equal(pol.forward(x), BatchedMLP(*w3, 2, 0, device="cuda:0", **_prec_kw(prec)).forward(x))
 
 
 def test_packed_w2_must_be_aligned(torch):

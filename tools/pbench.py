@@ -24,7 +24,8 @@ def rnd_policy(kind, N, d, dev, precision="f32"):
     else:
         h1 = h2 = 200; nout = 1; ok, sk = 0, 0
     return BatchedMLP(r(N, d, h1), r(N, h1), r(N, h1, h2), r(N, h2), r(N, h2, nout), r(N, nout), ok, sk, device=dev, precision=precision,
-                      pack_w2={"0": False, "1": True}.get(os.environ.get("PB_PACK", "1"), os.environ.get("PB_PACK"))), (h1, h2, nout)
+                      pack_w2={"0": False, "1": True}.get(os.environ.get("PB_PACK", "1"), os.environ.get("PB_PACK")),
+                      split_kernel=bool(os.environ.get("PB_SPLIT"))), (h1, h2, nout)   # PB_SPLIT=1: f16x2 on the split kernel of rounds 2-5
     # PB_PACK=0: the plain [N, h1, h2] layer 2; PB_PACK=fragments: the fragment-packed layer 2 of rounds 3-5 (default: the row-tile stream)
 
 
