@@ -41,11 +41,14 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRows = 32;                // env rows per workgroup (32-row tiles x 4 feature waves each)
 constexpr int kThreadsF = kRows * 8;
 constexpr int kMaxOut = 32;
 
 long long *g_policy_trace = nullptr;     // developer trace builds (kTrace, common.hpp) only: [workgroups][4 waves][8] timestamps
+// (mlp3_rt16_kernel: [workgroups][4 waves][64] stamps -- tools/trace_rt16.py)
+#define PT64(k) do { if (kTrace && a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define PT(k) do { if (kTrace && a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 struct FinishArgs {
@@ -1652,16 +1655,17 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
 // (wave w owns output chunks w, w + 4, ... of two row tiles): no layer-1 work and no relu + split repeated by four waves, no
 // 4-3-3-3 dealing of 13 chunks -- 1053 instead of 1500 matrix instructions per 32 rows at h = 400 -- and HALF the weight bytes per
 // matrix instruction, because the four waves of a workgroup consume the SAME stream: it travels global -> LDS once per workgroup,
-// into a ring of kR16Depth super-stages of four 4-KiB blocks; wave w requests piece w of every block.  One s_barrier per super-stage
-// (24 matrix instructions) orders it: a wave that is about to read the first block of super-stage S has waited for its own pieces of
-// S (counted vmcnt) and holds all of S - 1 in registers, so behind the barrier S is complete in LDS and the slot of S - 1 is free
-// for super-stage S + 2.  No other barrier after the prologue.
+// into a ring of kR16Depth = 4 super-stages of four 4-KiB blocks; wave w requests piece w of every block.  One s_barrier per
+// super-stage (24 matrix instructions) orders it: a wave that is about to read the first block of super-stage S has waited for its own
+// pieces of S (counted vmcnt), so behind the barrier S is complete in LDS; and every wave has consumed all of S - 2 (its reads of
+// S - 1's last block may still be in flight: nobody drains its LDS queue for the barrier), so the slot of S - 2 takes super-stage
+// S + 2.  No other barrier after the prologue.
 // One agent's stream (blocks of four 1-KiB pieces [64 lanes][8 float16]; policies.py: pack_f16_rowtile_stream):
 //   per pass p (output chunks S_p):  for c1:  L1(c1) = (W1 hi, W1 lo, 0, 0) of chunk c1 (one 16-wide k-step, linear k order),
 //                                             L2(c1, c2) = (hi, lo of k-step 2 c1), (hi, lo of k-step 2 c1 + 1) for c2 in S_p
 //                                             (accumulator k order: 16 s + 8 (j >> 2) + 4 half + (j & 3));
-//   padded to whole super-stages, then two empty super-stages.  Weights carry DroneMlpBf16.wscale like the split kernel's.
-constexpr int kR16Depth = 3;
+//   padded to whole super-stages, then three empty super-stages (the requests run two super-stages ahead, the reads one block).  Weights carry DroneMlpBf16.wscale like the split kernel's.
+constexpr int kR16Depth = 4;
 
 struct MArgsR16 {
     int E, N, d_in, h1, h2, nout, nc1, nc2, blocks;
@@ -1669,6 +1673,7 @@ struct MArgsR16 {
     const char *ws;
     FinishArgs fin;
     unsigned rb_magic;
+    long long *trace;                                             // developer trace builds only (tools/trace_rt16.py)
 };
 
 __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E, int N, int d_in, const MArgsR16 rest)
@@ -1685,6 +1690,8 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
     const int e0 = row_block * kRtRows + 32 * wave;                // this wave's 32 env rows (a wave without rows runs on clamped ones:
     const int half = lane >> 5;                                    // every wave takes part in every barrier)
     const int nc1 = a.nc1, nc2 = a.nc2;
+    PT64(0);
+    if (kTrace && a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 64 + 32] = __builtin_amdgcn_s_memrealtime();
     float ws1 = 1.0f, ws2 = 1.0f, wi1 = 1.0f, wi2 = 1.0f;
     if (a.wscale != nullptr) {
         ws1 = a.wscale[3 * (size_t)agent]; ws2 = a.wscale[3 * (size_t)agent + 1];
@@ -1702,7 +1709,7 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
     const unsigned ring_a = lds_addr(ring);
     const unsigned rd_a = ring_a + voff;
     auto dma_super = [&](int sst) {                                // this wave's four pieces of super-stage sst
-        const unsigned slot = ring_a + (unsigned)(sst % kR16Depth) * 16384u + (unsigned)wave * 1024u;
+        const unsigned slot = ring_a + (unsigned)(sst & (kR16Depth - 1)) * 16384u + (unsigned)wave * 1024u;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const unsigned long long src = sbase0 + (unsigned long long)(unsigned)(4 * sst + b) * 4096ull;
@@ -1711,21 +1718,35 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
         }
     };
 #pragma unroll 1
-    for (int sst = 0; sst < kR16Depth; ++sst) dma_super(sst);      // primed ahead of the prologue's own loads
+    for (int sst = 0; sst < 3; ++sst) dma_super(sst);              // primed ahead of the prologue's own loads
 
-    for (int i = tid; i < (nc1 + nc2) * 32; i += 256) {            // (clamped address, masked value: no branch around the loads)
-        const bool l1 = i < nc1 * 32;
-        const int j = l1 ? i : i - nc1 * 32, h = l1 ? a.h1 : a.h2;
-        const float v = (l1 ? a.b1 : a.b2)[(size_t)agent * h + min(j, h - 1)];
-        sb1[i] = __uint_as_float(__float_as_uint(v) & (j < h ? 0xffffffffu : 0u)) * (l1 ? ws1 : ws2);
-        if (!l1) {
-            f32x4 wv;
+    // biases and W3 -> LDS: at most four entries per thread (h1, h2 <= 512), every load requested before the first store (clamped
+    // addresses, masked values: no branch around the loads).  The W3 rows carry 1 / (layer 2's weight factor), a power of two.
+    {
+        const int total = (nc1 + nc2) * 32;
+        float bv[4];
+        f32x4 wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(tid + 256 * u, total - 1);
+            const bool l1 = i < nc1 * 32;
+            const int j = l1 ? i : i - nc1 * 32, h = l1 ? a.h1 : a.h2;
+            const float v = (l1 ? a.b1 : a.b2)[(size_t)agent * h + min(j, h - 1)];
+            bv[u] = __uint_as_float(__float_as_uint(v) & (j < h ? 0xffffffffu : 0u)) * (l1 ? ws1 : ws2);
+            const size_t row = (size_t)agent * a.h2 + (l1 ? 0 : min(j, a.h2 - 1));
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                const float t = a.w3[((size_t)agent * a.h2 + min(j, a.h2 - 1)) * a.nout + min(o, a.nout - 1)];
-                wv[o] = __uint_as_float(__float_as_uint(t) & ((j < a.h2 && o < a.nout) ? 0xffffffffu : 0u));
+                const float t = a.w3[row * a.nout + min(o, a.nout - 1)];
+                wv[u][o] = __uint_as_float(__float_as_uint(t) & ((j < a.h2 && o < a.nout) ? 0xffffffffu : 0u)) * wi2;
             }
-            sw3[j] = wv;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = tid + 256 * u;
+            if (i < total) {
+                sb1[i] = bv[u];
+                if (i >= nc1 * 32) sw3[i - nc1 * 32] = wv[u];
+            }
         }
     }
     // the x operand of layer 1 (one 16-wide k-step, linear order: inputs 8 half + j of row lane & 31), split once
@@ -1766,11 +1787,13 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's loads and its pieces of the first three super-stages
     __syncthreads();                                               // ... and everybody else's: biases, W3 and the ring are in LDS
+    PT64(1);
 
     // ---- consumption.  wf[0..3] = the current block's pieces (k-step 0 hi, lo; k-step 1 hi, lo); a piece is re-read with the NEXT
     // block's bytes right behind its last product.  `cur` = index of the block whose pieces are being (re)loaded.
     u32x4 wf[4];
     int cur = 0;
+    unsigned ra = rd_a;                                            // this lane's address of block `cur` in the ring
     // (requested in the order the pieces are consumed -- lo, hi of k-step 0, then lo, hi of k-step 1 -- so that the piece about to
     // be used is always the OLDEST of at most four reads in flight: every wait below is lgkmcnt(3))
     asm volatile("ds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %0, %4\n\tds_read_b128 %3, %4 offset:3072\n\tds_read_b128 %2, %4 offset:2048"
@@ -1778,19 +1801,19 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
     // the first read of a block: when it opens super-stage sst >= 1, the workgroup meets first (see the header)
     auto open_block = [&]() {
         ++cur;
+        ra = rd_a + ((unsigned)cur & (4u * kR16Depth - 1u)) * 4096u;
         if ((cur & 3) == 0) {
             const int sst = cur >> 2;
-            // this wave's pieces of sst have landed (sst + 1's four may be out), and its reads of sst - 1's last block are complete
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");       // this wave's pieces of sst have landed (sst + 1's four may be out)
             __builtin_amdgcn_s_barrier();
-            dma_super(sst + kR16Depth - 1);                        // the slot of sst - 1: every wave holds its last block in registers
+            dma_super(sst + 2);                                    // the slot of sst - 2: every wave is past its last block
         }
     };
     // (immediate offsets per piece: four variants by name)
     auto ring_read_p = [&](u32x4 &dst, auto PIECE) {
         constexpr int piece = decltype(PIECE)::value;
-        const unsigned ra = rd_a + (unsigned)((cur >> 2) % kR16Depth) * 16384u + (unsigned)(cur & 3) * 4096u;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(ra), "n"(piece * 1024) : "memory");
+        const unsigned at = ra;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(at), "n"(piece * 1024) : "memory");
     };
     typedef std::integral_constant<int, 0> P0; typedef std::integral_constant<int, 1> P1;
     typedef std::integral_constant<int, 2> P2; typedef std::integral_constant<int, 3> P3;
@@ -1816,57 +1839,76 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
         ring_read_p(wf[hi], HI);
     };
 
-    f32x4 ya = {0.0f, 0.0f, 0.0f, 0.0f}, yb = ya;                  // layer 3 (vector ALU): this lane's partial sums of the outputs
+    // layer 3 (vector ALU): this lane's partial sums of the outputs as two packed pairs (v_pk_fma_f32: two outputs per instruction),
+    // two chains (even / odd chunks)
+    f32x2 ya[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, yb[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
     const int passes = rt_passes(nc2), per = rt_per_pass(nc2);
     for (int p = 0; p < passes; ++p) {
         const int c2_0 = p * per, npc = min(per, nc2 - c2_0);
         f32x16 acc2[kRtChunks];
 #pragma unroll
         for (int i = 0; i < kRtChunks; ++i) acc2[i] = bias_tile(sb2 + min(c2_0 + i, nc2 - 1) * 32, lane);
-        for (int c1 = 0; c1 < nc1; ++c1) {
-            // layer 1 of chunk c1 (block L1: pieces 0, 1 = W1 hi, lo; 2, 3 unused), then relu + split -> the two k-steps' B operands
+        // in-chunk c1: layer 1 (block L1: pieces 0, 1 = W1 hi, lo; 2, 3 unused), relu + split -> the two k-steps' B operands, then its
+        // two k-steps of every output chunk of the pass.  FULL: the chunk holds 32 features (every chunk but a ragged last one, whose
+        // second k-step is empty when it has <= 16: the test is compiled only into the last chunk's copy of the code)
+        auto in_chunk = [&](int c1, auto FULL) {
             f32x16 a1 = bias_tile(sb1 + c1 * 32, lane);
             kstep(a1, xB, P0{}, P1{}, std::true_type{}, true);
             kstep(a1, xB, P2{}, P3{}, std::false_type{}, false);
             Parts<P> hB0, hB1;
             { SplitJob<S, 0, 1> j(a1, hB0, wi1); j.all(); }
             { SplitJob<S, 1, 1> j(a1, hB1, wi1); j.all(); }
-            const int kv = a.h1 - 32 * c1;                         // features of this in-chunk: a ragged last chunk of <= 16 has no second k-step
+            const bool second = decltype(FULL)::value ? true : a.h1 - 32 * c1 > 16;
 #pragma unroll
             for (int i = 0; i < kRtChunks; ++i) {
                 if (i < npc) {
                     kstep(acc2[i], hB0, P0{}, P1{}, std::true_type{}, true);
-                    kstep(acc2[i], hB1, P2{}, P3{}, std::false_type{}, kv > 16);
+                    kstep(acc2[i], hB1, P2{}, P3{}, std::false_type{}, second);
                 }
             }
-        }
-        // layer 3 on the vector ALU, exact float32: relu, undo layer 2's weight factor, 16 features x nout <= 4 per chunk
+        };
+        for (int c1 = 0; c1 < nc1 - 1; ++c1) { in_chunk(c1, std::true_type{}); PT64(2 + 14 * min(p, 1) + min(c1, 12)); }
+        in_chunk(nc1 - 1, std::false_type{});
+        PT64(2 + 14 * min(p, 1) + min(nc1 - 1, 12));
+        // layer 3 on the vector ALU, exact float32: relu (the weight factor of layer 2 is undone by the table), 16 features x nout <= 4
+        // per chunk and lane: per feature pair two v_max and four packed multiply-adds (the pair's relu'd values are the low / high
+        // half of one 64-bit operand)
 #pragma unroll
         for (int i = 0; i < kRtChunks; ++i) {
             if (i < npc) {
                 const f32x4 *wp = sw3 + 32 * (c2_0 + i) + 4 * half;
-                f32x4 part = {0.0f, 0.0f, 0.0f, 0.0f};           // this chunk's contribution (two chains: even / odd chunks)
+                f32x2 (&y)[2] = (i & 1) ? yb : ya;
+                f32x4 w3r[16];                                    // the chunk's 16 table rows of this lane, requested together
+#pragma unroll
+                for (int k = 0; k < 16; ++k) w3r[k] = wp[8 * (k >> 2) + (k & 3)];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float hv = fmaxf(acc2[i][4 * q + j], 0.0f) * wi2;
-                        const f32x4 wv = wp[8 * q + j];
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) part[o] = fmaf(wv[o], hv, part[o]);
+                    for (int j = 0; j < 4; j += 2) {
+                        f32x2 hv;
+                        asm("v_max_f32 %0, 0, %1" : "=v"(hv.x) : "v"(acc2[i][4 * q + j]));
+                        asm("v_max_f32 %0, 0, %1" : "=v"(hv.y) : "v"(acc2[i][4 * q + j + 1]));
+                        const f32x4 w0 = w3r[4 * q + j], w1 = w3r[4 * q + j + 1];
+                        const f32x2 w0a = {w0[0], w0[1]}, w0b = {w0[2], w0[3]}, w1a = {w1[0], w1[1]}, w1b = {w1[2], w1[3]};
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(y[0]) : "v"(w0a), "v"(hv));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(y[1]) : "v"(w0b), "v"(hv));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(y[0]) : "v"(w1a), "v"(hv));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(y[1]) : "v"(w1b), "v"(hv));
                     }
                 }
-                if (i & 1) yb += part; else ya += part;
             }
         }
+        PT64(15 + 14 * min(p, 1));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // no DMA may land late: the output tile reuses the ring
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // no DMA may land late: the output tile reuses the ring
     __syncthreads();                                               // ... and no wave may still be reading it
+    PT64(30);
 
     float *st = reinterpret_cast<float *>(ring) + wave * (32 * 33);
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
-        const float pv = ya[o] + yb[o];
+        const float pv = ya[o >> 1][o & 1] + yb[o >> 1][o & 1];
         const float other = __shfl_xor(pv, 32, 64);
         if (half == 0) st[(lane & 31) * 33 + o] = pv + other;
     }
@@ -1887,6 +1929,8 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
             finish_quad(a.fin, yv, e, agent, part, tval[it], epval[it]);
         }
     }
+    PT64(31);
+    if (kTrace && a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 64 + 33] = __builtin_amdgcn_s_memrealtime();   // (100 MHz)
 }
 
 // > 64 KiB of dynamic LDS must be opted into once per (kernel, device): a bit mask of device ordinals per kernel,
@@ -2111,6 +2155,7 @@ extern "C" int dronesim_mlp_forward_f16x2_rt(const DroneMlpBf16 *m, const float 
     r.x = x; r.b1 = m->b1; r.b2 = m->b2; r.b3 = m->b3; r.w3 = reinterpret_cast<const float *>(m->w3p); r.wscale = m->wscale;
     r.ws = reinterpret_cast<const char *>(m->w1p);
     r.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
+    r.trace = kTrace ? g_policy_trace : nullptr;
     const size_t lds = (size_t)(r.nc1 + r.nc2) * 32 * 4 + (size_t)r.nc2 * 32 * 16 + (size_t)kR16Depth * 16384;
     {
         static std::mutex mu;
