@@ -387,19 +387,22 @@ int dronesim_mlp_forward_f16x2(const DroneMlpBf16 *m, const float *x, float *out
                                uint64_t seed, uint64_t counter, int64_t env_base,
                                const int32_t *t, const int32_t *episode, int E, void *stream);
 
-/* f16x2 with ROW-TILE ownership (0.6.0; d_in <= 16, nout <= 4: the reference's Gaussian actor and critic): a wave owns 32 env rows
- * and every output chunk, the four waves of a workgroup share one weight ring, layer 3 runs in exact float32 on the vector ALU.
- * Same arithmetic contract as dronesim_mlp_forward_f16x2 (two-part float16 split, three products, float32 accumulation).
- * DroneMlpBf16 fields as there, except:
- *   w1p      = ONE stream per agent, [N][B][4][64][8] float16 with B = dronesim_mlp_rt16_blocks(h1, h2) blocks of four 1-KiB pieces
- *              ([lane = 32 half + i][8]), weights multiplied by wscale like the split image:
+/* f16x2 with ROW-TILE ownership (0.6.0; d_in <= 16): a wave owns 32 env rows and every output chunk of layer 2, the four waves of a
+ * workgroup share one weight ring; layer 3 runs in exact float32 on the vector ALU when nout <= 4 (the reference's Gaussian actor and
+ * critic) and on the matrix cores, from the split of the relu'd layer-2 tiles, otherwise.  Same arithmetic contract as
+ * dronesim_mlp_forward_f16x2 (two-part float16 split, three products, float32 accumulation).  DroneMlpBf16 fields as there, except:
+ *   w1p      = ONE stream per agent, [N][B][4][64][8] float16 with B = dronesim_mlp_rt16_blocks(h1, h2, nout) blocks of four 1-KiB
+ *              pieces ([lane = 32 half + i][8]), weights multiplied by wscale like the split image:
  *                passes P = ceil(C2 / 7), chunks per pass ceil(C2 / P); per pass p (output chunks S_p): for c1 < C1:
  *                  L1(c1)     = (W1 hi, W1 lo, 0, 0): piece[l][j] = part(W1[8 half + j][32 c1 + i])                (one 16-wide k-step)
  *                  L2(c1, c2) = (hi, lo of s = 2 c1), (hi, lo of s = 2 c1 + 1): piece[l][j] = part(W2[16 s + 8 (j >> 2) + 4 half + (j & 3)][32 c2 + i])
- *                for c2 in S_p; zero blocks up to B;
- *   w3p      = the plain float32 [N][h2][nout] output layer (NOT multiplied by wscale; wscale[i][2] is not used);
- *   reserved = dronesim_mlp_rt16_blocks(h1, h2).                                                                             */
-int dronesim_mlp_rt16_blocks(int h1, int h2);
+ *                for c2 in S_p; then, nout > 4 only, for c2 in S_p:
+ *                  L3(c2)     = (hi, lo of s = 2 c2), (hi, lo of s = 2 c2 + 1): piece[l][j] = part(W3[16 s + 8 (j >> 2) + 4 half + (j & 3)][i])
+ *                (outputs i >= nout zero); zero blocks up to B;
+ *   w3p      = nout <= 4: the plain float32 [N][h2][nout] output layer (NOT multiplied by wscale; wscale[i][2] is not used);
+ *              nout > 4: not read;
+ *   reserved = dronesim_mlp_rt16_blocks(h1, h2, nout).                                                                       */
+int dronesim_mlp_rt16_blocks(int h1, int h2, int nout);
 int dronesim_mlp_forward_f16x2_rt(const DroneMlpBf16 *m, const float *x, float *out, float *act, int32_t *act_idx,
                                   uint64_t seed, uint64_t counter, int64_t env_base,
                                   const int32_t *t, const int32_t *episode, int E, void *stream);

@@ -136,7 +136,7 @@ def lib():
     L.dronesim_mlp_forward_f16x2.restype = C.c_int
     L.dronesim_mlp_bf16x3_stages.argtypes = [C.c_int, C.c_int]
     L.dronesim_mlp_rt_blocks.argtypes = [C.c_int, C.c_int, C.c_int]
-    L.dronesim_mlp_rt16_blocks.argtypes = [C.c_int, C.c_int]
+    L.dronesim_mlp_rt16_blocks.argtypes = [C.c_int, C.c_int, C.c_int]
     L.dronesim_mlp_forward_f16x2_rt.argtypes = L.dronesim_mlp_forward_bf16.argtypes
     L.dronesim_mlp_forward_f16x2_rt.restype = C.c_int
     L.dronesim_mlp_bf16x3_stages.restype = C.c_int

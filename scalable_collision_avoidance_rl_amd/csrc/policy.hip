@@ -1651,7 +1651,8 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
 // Two-part float16 split (f16x2), ROW-TILE ownership with ONE weight ring per workgroup (round 6; dronesim_mlp_forward_f16x2_rt).
 // The formulation of mlp3_rt_kernel on v_mfma_f32_32x32x16_f16: a wave owns 32 env rows of one agent and every output chunk of layer 2
 // for them (kRtChunks accumulator tiles per pass, layer 1 recomputed in the second pass), layers meet in registers through the
-// float16 split of the accumulator tile, layer 3 (nout <= 4) runs on the vector ALU in exact float32.  Against mlp3_split_kernel
+// float16 split of the accumulator tile, layer 3 runs on the vector ALU in exact float32 (VL3: nout <= 4) or takes the split, relu'd
+// layer-2 tiles as the B operand of its own blocks.  Against mlp3_split_kernel
 // (wave w owns output chunks w, w + 4, ... of two row tiles): no layer-1 work and no relu + split repeated by four waves, no
 // 4-3-3-3 dealing of 13 chunks -- 1053 instead of 1500 matrix instructions per 32 rows at h = 400 -- and HALF the weight bytes per
 // matrix instruction, because the four waves of a workgroup consume the SAME stream: it travels global -> LDS once per workgroup,
@@ -1664,6 +1665,8 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt_kernel(const float *x, int E, 
 //   per pass p (output chunks S_p):  for c1:  L1(c1) = (W1 hi, W1 lo, 0, 0) of chunk c1 (one 16-wide k-step, linear k order),
 //                                             L2(c1, c2) = (hi, lo of k-step 2 c1), (hi, lo of k-step 2 c1 + 1) for c2 in S_p
 //                                             (accumulator k order: 16 s + 8 (j >> 2) + 4 half + (j & 3));
+//                                    nout > 4 (layer 3 on the matrix cores), after the pass's in-chunks:  L3(c2) = (hi, lo of k-step 2 c2),
+//                                             (hi, lo of k-step 2 c2 + 1) of W3^T, outputs zero-padded to 32, for c2 in S_p;
 //   padded to whole super-stages, then three empty super-stages (the requests run two super-stages ahead, the reads one block).  Weights carry DroneMlpBf16.wscale like the split kernel's.
 constexpr int kR16Depth = 4;
 
@@ -1676,6 +1679,7 @@ struct MArgsR16 {
     long long *trace;                                             // developer trace builds only (tools/trace_rt16.py)
 };
 
+template <bool VL3>
 __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E, int N, int d_in, const MArgsR16 rest)
 {
     typedef SchemeF16x2 S;
@@ -1692,15 +1696,16 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
     const int nc1 = a.nc1, nc2 = a.nc2;
     PT64(0);
     if (kTrace && a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 64 + 32] = __builtin_amdgcn_s_memrealtime();
-    float ws1 = 1.0f, ws2 = 1.0f, wi1 = 1.0f, wi2 = 1.0f;
+    float ws1 = 1.0f, ws2 = 1.0f, wi1 = 1.0f, wi2 = 1.0f, wi3 = 1.0f;
     if (a.wscale != nullptr) {
         ws1 = a.wscale[3 * (size_t)agent]; ws2 = a.wscale[3 * (size_t)agent + 1];
         wi1 = __builtin_amdgcn_rcpf(ws1); wi2 = __builtin_amdgcn_rcpf(ws2);
+        if constexpr (!VL3) wi3 = __builtin_amdgcn_rcpf(a.wscale[3 * (size_t)agent + 2]);
     }
     float *sb1 = reinterpret_cast<float *>(smem);                  // b1 * ws1 | b2 * ws2, zero padded to whole chunks
     float *sb2 = sb1 + nc1 * 32;
-    f32x4 *sw3 = reinterpret_cast<f32x4 *>(sb2 + nc2 * 32);        // W3[f][0..3] (float32, unscaled; zero beyond h2 / nout)
-    char *ring = reinterpret_cast<char *>(sw3 + nc2 * 32);         // [kR16Depth][4 blocks][4 pieces][1 KiB], shared by the workgroup
+    f32x4 *sw3 = reinterpret_cast<f32x4 *>(sb2 + nc2 * 32);        // VL3: W3[f][0..3] / layer 2's weight factor (zero beyond h2 / nout)
+    char *ring = reinterpret_cast<char *>(sw3 + (VL3 ? nc2 * 32 : 0));   // [kR16Depth][4 blocks][4 pieces][1 KiB], shared by the workgroup
 
     // ---- the weight stream: wave w requests piece w of every block (scalar base + this lane's 16-byte slot, by name)
     const unsigned long long sbase0 = reinterpret_cast<unsigned long long>(a.ws) + (unsigned long long)agent * a.blocks * 4096ull +
@@ -1733,11 +1738,13 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
             const int j = l1 ? i : i - nc1 * 32, h = l1 ? a.h1 : a.h2;
             const float v = (l1 ? a.b1 : a.b2)[(size_t)agent * h + min(j, h - 1)];
             bv[u] = __uint_as_float(__float_as_uint(v) & (j < h ? 0xffffffffu : 0u)) * (l1 ? ws1 : ws2);
-            const size_t row = (size_t)agent * a.h2 + (l1 ? 0 : min(j, a.h2 - 1));
+            if constexpr (VL3) {
+                const size_t row = (size_t)agent * a.h2 + (l1 ? 0 : min(j, a.h2 - 1));
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                const float t = a.w3[row * a.nout + min(o, a.nout - 1)];
-                wv[u][o] = __uint_as_float(__float_as_uint(t) & ((j < a.h2 && o < a.nout) ? 0xffffffffu : 0u)) * wi2;
+                for (int o = 0; o < 4; ++o) {
+                    const float t = a.w3[row * a.nout + min(o, a.nout - 1)];
+                    wv[u][o] = __uint_as_float(__float_as_uint(t) & ((j < a.h2 && o < a.nout) ? 0xffffffffu : 0u)) * wi2;
+                }
             }
         }
 #pragma unroll
@@ -1745,7 +1752,7 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
             const int i = tid + 256 * u;
             if (i < total) {
                 sb1[i] = bv[u];
-                if (i >= nc1 * 32) sw3[i - nc1 * 32] = wv[u];
+                if (VL3 && i >= nc1 * 32) sw3[i - nc1 * 32] = wv[u];
             }
         }
     }
@@ -1842,6 +1849,10 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
     // layer 3 (vector ALU): this lane's partial sums of the outputs as two packed pairs (v_pk_fma_f32: two outputs per instruction),
     // two chains (even / odd chunks)
     f32x2 ya[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, yb[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    // nout > 4: layer 3 on the matrix cores, out^T[output][row] in two accumulator tiles (even / odd chunks)
+    f32x16 y3a, y3b;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { y3a[r] = 0.0f; y3b[r] = 0.0f; }
     const int passes = rt_passes(nc2), per = rt_per_pass(nc2);
     for (int p = 0; p < passes; ++p) {
         const int c2_0 = p * per, npc = min(per, nc2 - c2_0);
@@ -1873,6 +1884,25 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
         // layer 3 on the vector ALU, exact float32: relu (the weight factor of layer 2 is undone by the table), 16 features x nout <= 4
         // per chunk and lane: per feature pair two v_max and four packed multiply-adds (the pair's relu'd values are the low / high
         // half of one 64-bit operand)
+        if constexpr (!VL3) {
+            // the pass's blocks L3(c2): the relu'd, split chunk is the B operand of its two k-steps, W3^T (outputs zero-padded to 32) the A
+#pragma unroll
+            for (int i = 0; i < kRtChunks; ++i) {
+                if (i < npc) {
+                    Parts<P> gB0, gB1;
+                    { SplitJob<S, 0, 1> j(acc2[i], gB0, wi2); j.all(); }
+                    { SplitJob<S, 1, 1> j(acc2[i], gB1, wi2); j.all(); }
+                    const bool second = a.h2 - 32 * (c2_0 + i) > 16;
+                    if (i & 1) {
+                        kstep(y3b, gB0, P0{}, P1{}, std::true_type{}, true);
+                        kstep(y3b, gB1, P2{}, P3{}, std::false_type{}, second);
+                    } else {
+                        kstep(y3a, gB0, P0{}, P1{}, std::true_type{}, true);
+                        kstep(y3a, gB1, P2{}, P3{}, std::false_type{}, second);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < kRtChunks; ++i) {
             if (i < npc) {
@@ -1899,6 +1929,7 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
                 }
             }
         }
+        }
         PT64(15 + 14 * min(p, 1));
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // no DMA may land late: the output tile reuses the ring
@@ -1906,11 +1937,16 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
     PT64(30);
 
     float *st = reinterpret_cast<float *>(ring) + wave * (32 * 33);
+    if constexpr (VL3) {
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        const float pv = ya[o >> 1][o & 1] + yb[o >> 1][o & 1];
-        const float other = __shfl_xor(pv, 32, 64);
-        if (half == 0) st[(lane & 31) * 33 + o] = pv + other;
+        for (int o = 0; o < 4; ++o) {
+            const float pv = ya[o >> 1][o & 1] + yb[o >> 1][o & 1];
+            const float other = __shfl_xor(pv, 32, 64);
+            if (half == 0) st[(lane & 31) * 33 + o] = pv + other;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[(lane & 31) * 33 + cd_row(r, lane)] = (y3a[r] + y3b[r]) * wi3;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1950,6 +1986,17 @@ int enable_big_lds(const void *kernel, unsigned long long (&opted)[4], std::mute
         return dronesim_fail(DRONESIM_ELAUNCH, msg);
     }
     opted[dev >> 6] |= 1ull << (dev & 63);
+    return DRONESIM_OK;
+}
+
+template <bool VL3>
+int launch_rt16(const MArgsR16 &r, dim3 grid, size_t lds, hipStream_t stream)
+{
+    static std::mutex mu;
+    static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
+    const int rc = enable_big_lds(reinterpret_cast<const void *>(mlp3_rt16_kernel<VL3>), opted, mu, "mlp3_rt16_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp3_rt16_kernel<VL3>, grid, dim3(256), lds, stream, r.x, r.E, r.N, r.d_in, r);
     return DRONESIM_OK;
 }
 
@@ -2125,11 +2172,11 @@ extern "C" int dronesim_mlp_forward_f16x2(const DroneMlpBf16 *m, const float *x,
 
 // blocks (4 KiB) of one agent's float16 row-tile stream (dronesim_mlp_forward_f16x2_rt): the real blocks rounded up to whole
 // super-stages of four, plus three super-stages of padding for the run-ahead of the DMA requests
-extern "C" int dronesim_mlp_rt16_blocks(int h1, int h2)
+extern "C" int dronesim_mlp_rt16_blocks(int h1, int h2, int nout)
 {
-    if (h1 < 1 || h2 < 1) return 0;
+    if (h1 < 1 || h2 < 1 || nout < 1) return 0;
     const int nc1 = (h1 + 31) / 32, nc2 = (h2 + 31) / 32;
-    const int real = rt_passes(nc2) * nc1 + nc1 * nc2;
+    const int real = rt_passes(nc2) * nc1 + nc1 * nc2 + (nout > 4 ? nc2 : 0);
     return ((real + 3) / 4 + 3) * 4;
 }
 
@@ -2140,11 +2187,12 @@ extern "C" int dronesim_mlp_forward_f16x2_rt(const DroneMlpBf16 *m, const float 
     if (!m || !x) return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: NULL argument");
     const int rc = check_mlp("f16x2_rt", m->N, m->d_in, m->h1, m->h2, m->nout, m->out_kind, m->sample_kind, E);
     if (rc) return rc;
-    if (m->d_in > 16 || m->nout > 4) return dronesim_fail(DRONESIM_EUNSUPPORTED, "dronesim_mlp_forward_f16x2_rt: d_in <= 16 and nout <= 4");
-    if (!m->w1p || !m->w3p || !m->b1 || !m->b2 || !m->b3)
+    if (m->d_in > 16) return dronesim_fail(DRONESIM_EUNSUPPORTED, "dronesim_mlp_forward_f16x2_rt: d_in <= 16");
+    const bool vl3 = m->nout <= 4;                                // layer 3 on the vector ALU, from the plain float32 array
+    if (!m->w1p || (vl3 && !m->w3p) || !m->b1 || !m->b2 || !m->b3)
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: NULL weight array");
-    if (m->reserved != dronesim_mlp_rt16_blocks(m->h1, m->h2))
-        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: DroneMlpBf16.reserved must hold dronesim_mlp_rt16_blocks(h1, h2)");
+    if (m->reserved != dronesim_mlp_rt16_blocks(m->h1, m->h2, m->nout))
+        return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: DroneMlpBf16.reserved must hold dronesim_mlp_rt16_blocks(h1, h2, nout)");
     if ((reinterpret_cast<uintptr_t>(m->w1p) & 15u) != 0)
         return dronesim_fail(DRONESIM_EINVAL, "dronesim_mlp_forward_f16x2_rt: the stream must be 16-byte aligned");
     if (E == 0) return DRONESIM_OK;
@@ -2156,17 +2204,13 @@ extern "C" int dronesim_mlp_forward_f16x2_rt(const DroneMlpBf16 *m, const float 
     r.ws = reinterpret_cast<const char *>(m->w1p);
     r.fin = make_finish(m->N, m->nout, m->out_kind, m->sample_kind, out, act, act_idx, seed, counter, env_base, t, episode);
     r.trace = kTrace ? g_policy_trace : nullptr;
-    const size_t lds = (size_t)(r.nc1 + r.nc2) * 32 * 4 + (size_t)r.nc2 * 32 * 16 + (size_t)kR16Depth * 16384;
-    {
-        static std::mutex mu;
-        static unsigned long long opted[4] = {0ull, 0ull, 0ull, 0ull};
-        const int lrc = enable_big_lds(reinterpret_cast<const void *>(mlp3_rt16_kernel), opted, mu, "mlp3_rt16_kernel");
-        if (lrc) return lrc;
-    }
+    const size_t lds = (size_t)(r.nc1 + r.nc2) * 32 * 4 + (vl3 ? (size_t)r.nc2 * 32 * 16 : 0) + (size_t)kR16Depth * 16384;
     const unsigned rb = (unsigned)((E + kRtRows - 1) / kRtRows);
     const dim3 grid(rb * m->N);
     r.rb_magic = div_magic(grid.x, rb);
-    hipLaunchKernelGGL(mlp3_rt16_kernel, grid, dim3(256), lds, static_cast<hipStream_t>(stream), r.x, r.E, r.N, r.d_in, r);
+    const int lrc = vl3 ? launch_rt16<true>(r, grid, lds, static_cast<hipStream_t>(stream))
+                        : launch_rt16<false>(r, grid, lds, static_cast<hipStream_t>(stream));
+    if (lrc) return lrc;
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return dronesim_fail(DRONESIM_ELAUNCH, hipGetErrorString(e));
     return DRONESIM_OK;

@@ -230,26 +230,32 @@ def pack_f32_rowtile_stream(w1, b1, w2, w3):
     return torch.stack(seq, dim=1).contiguous()
 
 
-def pack_f16_rowtile_stream(w1, w2, blocks):
-    """[N, d_in, h1], [N, h1, h2] float32 (ALREADY multiplied by their power-of-two factors) -> the weight stream of the float16
-    row-tile kernel (`dronesim_mlp_forward_f16x2_rt`, csrc/policy.hip: mlp3_rt16_kernel): ``[N, blocks, 4, 64, 8]`` float16, blocks
-    of four 1-KiB pieces in the kernel's consumption order -- per pass (output chunks S_p), for every in-chunk c1: L1(c1) = (W1 hi, W1
-    lo, 0, 0), then L2(c1, c2) = (hi, lo of k-step 2 c1; hi, lo of k-step 2 c1 + 1) for c2 in S_p -- zero blocks up to `blocks`."""
+def pack_f16_rowtile_stream(w1, w2, blocks, w3=None):
+    """[N, d_in, h1], [N, h1, h2] (and, for nout > 4, [N, h2, nout]) float32 weights ALREADY multiplied by their power-of-two factors
+    -> the weight stream of the float16 row-tile kernel (`dronesim_mlp_forward_f16x2_rt`, csrc/policy.hip: mlp3_rt16_kernel):
+    ``[N, blocks, 4, 64, 8]`` float16, blocks of four 1-KiB pieces in the kernel's consumption order -- per pass (output chunks S_p),
+    for every in-chunk c1: L1(c1) = (W1 hi, W1 lo, 0, 0), then L2(c1, c2) = (hi, lo of k-step 2 c1; hi, lo of k-step 2 c1 + 1) for c2 in
+    S_p; with `w3` the pass ends with L3(c2) = (hi, lo of k-step 2 c2; hi, lo of k-step 2 c2 + 1) of W3 for c2 in S_p -- zero blocks up
+    to `blocks`."""
     import torch
     n, d_in, h1 = w1.shape
     h2 = w2.shape[2]
     nc1, nc2 = (h1 + 31) // 32, (h2 + 31) // 32
     f1 = pack_split_fragments(w1, 1, nc1, "linear", "f16x2")                    # [N, c1, 1, P, 64, 8]
     f2 = pack_split_fragments(w2, 2 * nc1, nc2, "accumulator", "f16x2")         # [N, c2, 2 c1 + s, P, 64, 8]
+    f3 = None if w3 is None else pack_split_fragments(w3, 2 * nc2, 1, "accumulator", "f16x2")   # [N, 1, 2 c2 + s, P, 64, 8]
     zero = torch.zeros_like(f1[:, 0, 0, 0])
     passes = (nc2 + RT_CHUNKS - 1) // RT_CHUNKS
     per = (nc2 + passes - 1) // passes
     seq = []
     for p in range(passes):
+        chunks = range(p * per, min(nc2, (p + 1) * per))
         for c1 in range(nc1):
             seq.append(torch.stack([f1[:, c1, 0, 0], f1[:, c1, 0, 1], zero, zero], dim=1))
-            for c2 in range(p * per, min(nc2, (p + 1) * per)):
+            for c2 in chunks:
                 seq.append(torch.stack([f2[:, c2, 2 * c1, 0], f2[:, c2, 2 * c1, 1], f2[:, c2, 2 * c1 + 1, 0], f2[:, c2, 2 * c1 + 1, 1]], dim=1))
+        for c2 in (chunks if f3 is not None else ()):
+            seq.append(torch.stack([f3[:, 0, 2 * c2, 0], f3[:, 0, 2 * c2, 1], f3[:, 0, 2 * c2 + 1, 0], f3[:, 0, 2 * c2 + 1, 1]], dim=1))
     assert len(seq) <= blocks - 12
     pad = torch.zeros_like(seq[0])
     seq += [pad] * (blocks - len(seq))
@@ -328,16 +334,16 @@ class BatchedMLP:
             self._wscale = None
             if precision == "f16x2":                               # power-of-two factors: the low parts stay normal float16
                 self._wscale = f16_weight_scales(self.w1, self.w2, self.w3)
-            # round 6: f16x2 with nout <= 4 (Gaussian actor, critic) takes the ROW-TILE kernel (one stream per agent, a ring per
-            # workgroup, layer 3 in exact float32 on the vector ALU); `split_kernel=True` keeps the split kernel of rounds 2-5
-            self._rt16 = precision == "f16x2" and self.nout <= 4 and not split_kernel
+            # round 6: f16x2 takes the ROW-TILE kernel (one stream per agent, a ring per workgroup; layer 3 in exact float32 on the
+            # vector ALU for nout <= 4, on the matrix cores otherwise); `split_kernel=True` keeps the split kernel of rounds 2-5
+            self._rt16 = precision == "f16x2" and not split_kernel
             if self._rt16:
-                stages = int(self._lib.dronesim_mlp_rt16_blocks(self.h1, self.h2))
+                stages = int(self._lib.dronesim_mlp_rt16_blocks(self.h1, self.h2, self.nout))
             self._w1p = self._split_image(stages)
             mb = _native.DroneMlpBf16()
             mb.N, mb.d_in, mb.h1, mb.h2, mb.nout = self.n_agents, self.d_in, self.h1, self.h2, self.nout
             mb.out_kind, mb.sample_kind, mb.reserved = self.out_kind, self.sample_kind, stages
-            mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), None, (self.w3.data_ptr() if self._rt16 else None)
+            mb.w1p, mb.w2p, mb.w3p = self._w1p.data_ptr(), None, (self.w3.data_ptr() if self._rt16 and self.nout <= 4 else None)
             mb.b1, mb.b2, mb.b3 = self.b1.data_ptr(), self.b2.data_ptr(), self.b3.data_ptr()
             mb.wscale = None if self._wscale is None else self._wscale.data_ptr()
             self._m = mb
@@ -363,7 +369,7 @@ class BatchedMLP:
             self._w2p.copy_(pack_bf16_fragments(self.w2, 2 * nc1, nc2))
             self._w3p.copy_(pack_bf16_fragments(self.w3, 2 * nc2, 1, k_order="accumulator"))
         else:
-            stages = int(self._lib.dronesim_mlp_rt16_blocks(self.h1, self.h2) if getattr(self, "_rt16", False)
+            stages = int(self._lib.dronesim_mlp_rt16_blocks(self.h1, self.h2, self.nout) if getattr(self, "_rt16", False)
                          else self._lib.dronesim_mlp_bf16x3_stages(self.h1, self.h2))
             if self._wscale is not None:
                 self._wscale.copy_(f16_weight_scales(self.w1, self.w2, self.w3))
@@ -375,7 +381,8 @@ class BatchedMLP:
         """The packed weight streams of the split precisions; f16x2: of the weights times their power-of-two factors."""
         if getattr(self, "_rt16", False):
             sc = self._wscale
-            return pack_f16_rowtile_stream(self.w1 * sc[:, 0, None, None], self.w2 * sc[:, 1, None, None], stages)
+            return pack_f16_rowtile_stream(self.w1 * sc[:, 0, None, None], self.w2 * sc[:, 1, None, None], stages,
+                                           self.w3 * sc[:, 2, None, None] if self.nout > 4 else None)
         if self._wscale is None:
             return pack_split_streams(self.w1, self.w2, self.w3, stages, self.precision)
         sc = self._wscale

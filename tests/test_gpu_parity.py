@@ -35,8 +35,8 @@ def env_for(fx, E):
 
 
 def _prec_kw(prec):
-    """BatchedMLP keywords of a test's precision label: "f16x2" with nout <= 4 runs the row-tile float16 kernel of round 6
-    (mlp3_rt16_kernel), "f16x2-split" keeps it on the split kernel of rounds 2-5 (which every other nout still takes)."""
+    """BatchedMLP keywords of a test's precision label: "f16x2" runs the row-tile float16 kernel of round 6 (mlp3_rt16_kernel: layer 3 on the
+    vector ALU for nout <= 4, on the matrix cores otherwise), "f16x2-split" the split kernel of rounds 2-5."""
     return dict(precision="f16x2", split_kernel=True) if prec == "f16x2-split" else dict(precision=prec)
 
 

@@ -37,7 +37,7 @@ for kind in gaussian softmax16 critic; do
 done
 # the float16 row-tile policy kernel (nout <= 4): stats CSV, split kernel vs row-tile same box, phase stamps, its own bench line
 PB_PREC=f16x2 PB_KINDS=gaussian prof c5_policy_f16x2_gaussian python $ROOT/tools/pbench.py c5
-(for sp in 1 "" 1 ""; do echo "# PB_SPLIT=$sp (1 = split kernel of rounds 2-5, empty = row-tile kernel)"; PB_SPLIT=$sp PB_PREC=f16x2 PB_KINDS=gaussian,critic $T python tools/pbench.py c5 c3 2>&1 | grep -v amdgpu.ids; done) > $OUT/${TAG}_pbench_f16x2_rowtile.log
+(for sp in 1 "" 1 ""; do echo "# PB_SPLIT=$sp (1 = split kernel of rounds 2-5, empty = row-tile kernel)"; PB_SPLIT=$sp PB_PREC=f16x2 PB_KINDS=gaussian,critic,softmax16 $T python tools/pbench.py c5 c3 2>&1 | grep -v amdgpu.ids; done) > $OUT/${TAG}_pbench_f16x2_rowtile.log
 [ -f abl/libdronesim_trace.so ] && (for k in gaussian critic; do DRONESIM_LIB=abl/libdronesim_trace.so $T python tools/trace_rt16.py $k c5 2>&1 | grep -v amdgpu.ids; done) > $OUT/${TAG}_trace_rt16.log
 $T python bench.py --workload c5 --policy gaussian --policy-precision f16x2 > $OUT/${TAG}_c5_gaussian_f16x2_bench.json 2>/dev/null
 # SQ counters of the C5-shard step kernel
