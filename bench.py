@@ -831,7 +831,7 @@ def main():
                                     ("c5_gaussian_f32", "c5", "gaussian", "f32"), ("c5_gaussian_bf16x3", "c5", "gaussian", "bf16x3"),
                                     ("c5_gaussian_f16x2", "c5", "gaussian", "f16x2"),
                                     ("c5_full_gaussian_f16x2", "c5_full", "gaussian", "f16x2"),   # configs[4]'s whole env axis WITH its policy, one rank
-                                    ("c3_softmax16_f32", "c3", "softmax16", "f32")):
+                                    ("c3_softmax16_f32", "c3", "softmax16", "f32"), ("c3_softmax16_f16x2", "c3", "softmax16", "f16x2")):
                 try:
                     other[key] = side_workload(torch, dev, wl, pk, precision=pr, default_construction=(key == "default_construction"))
                 except Exception as ex:                 # a side measurement must never cost the headline line

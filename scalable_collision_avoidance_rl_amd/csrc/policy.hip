@@ -1696,6 +1696,11 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
     const int nc1 = a.nc1, nc2 = a.nc2;
     PT64(0);
     if (kTrace && a.trace && lane == 0) a.trace[((size_t)blockIdx.x * 4 + wave) * 64 + 32] = __builtin_amdgcn_s_memrealtime();
+    if (kTrace && a.trace && lane == 0) {                          // where the workgroup runs: HW_ID (wave, simd, cu, sh, se ...) and the XCC
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        a.trace[((size_t)blockIdx.x * 4 + wave) * 64 + 34] = (long long)hw | ((long long)xcc << 32);
+    }
     float ws1 = 1.0f, ws2 = 1.0f, wi1 = 1.0f, wi2 = 1.0f, wi3 = 1.0f;
     if (a.wscale != nullptr) {
         ws1 = a.wscale[3 * (size_t)agent]; ws2 = a.wscale[3 * (size_t)agent + 1];
@@ -1722,59 +1727,32 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(voff), "s"(src) : "memory", "m0");
         }
     };
-#pragma unroll 1
-    for (int sst = 0; sst < 3; ++sst) dma_super(sst);              // primed ahead of the prologue's own loads
+    dma_super(0);                                                  // primed ahead of the prologue's own loads
 
-    // biases and W3 -> LDS: at most four entries per thread (h1, h2 <= 512), every load requested before the first store (clamped
-    // addresses, masked values: no branch around the loads).  The W3 rows carry 1 / (layer 2's weight factor), a power of two.
-    {
-        const int total = (nc1 + nc2) * 32;
-        float bv[4];
-        f32x4 wv[4];
+    // Prologue loads, all requested before anything waits: biases and W3 (at most four table entries per thread: h1, h2 <= 512; clamped
+    // addresses, masked values: no branch around the loads), the x rows, the sampling counters, b3 -- then super-stages 1 and 2, so
+    // that ONE counted wait (all but those eight requests) covers what the prologue needs and the first super-stage.
+    const int total = (nc1 + nc2) * 32;
+    float bv[4];
+    f32x4 wv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = min(tid + 256 * u, total - 1);
-            const bool l1 = i < nc1 * 32;
-            const int j = l1 ? i : i - nc1 * 32, h = l1 ? a.h1 : a.h2;
-            const float v = (l1 ? a.b1 : a.b2)[(size_t)agent * h + min(j, h - 1)];
-            bv[u] = __uint_as_float(__float_as_uint(v) & (j < h ? 0xffffffffu : 0u)) * (l1 ? ws1 : ws2);
-            if constexpr (VL3) {
-                const size_t row = (size_t)agent * a.h2 + (l1 ? 0 : min(j, a.h2 - 1));
+    for (int u = 0; u < 4; ++u) {
+        const int i = min(tid + 256 * u, total - 1);
+        const bool l1 = i < nc1 * 32;
+        const int j = l1 ? i : i - nc1 * 32, h = l1 ? a.h1 : a.h2;
+        bv[u] = (l1 ? a.b1 : a.b2)[(size_t)agent * h + min(j, h - 1)];
+        if constexpr (VL3) {
+            const size_t row = (size_t)agent * a.h2 + (l1 ? 0 : min(j, a.h2 - 1));
 #pragma unroll
-                for (int o = 0; o < 4; ++o) {
-                    const float t = a.w3[row * a.nout + min(o, a.nout - 1)];
-                    wv[u][o] = __uint_as_float(__float_as_uint(t) & ((j < a.h2 && o < a.nout) ? 0xffffffffu : 0u)) * wi2;
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = tid + 256 * u;
-            if (i < total) {
-                sb1[i] = bv[u];
-                if (VL3 && i >= nc1 * 32) sw3[i - nc1 * 32] = wv[u];
-            }
+            for (int o = 0; o < 4; ++o) wv[u][o] = a.w3[row * a.nout + min(o, a.nout - 1)];
         }
     }
-    // the x operand of layer 1 (one 16-wide k-step, linear order: inputs 8 half + j of row lane & 31), split once
-    Parts<P> xB;
+    float xv[8];
     {
         const int e = min(e0 + (lane & 31), a.E - 1);
         const float *xr = a.x + ((size_t)e * a.N + agent) * a.d_in;
-        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 8 * half + j;
-            const float xv = xr[min(k, a.d_in - 1)];
-            v[j] = __uint_as_float(__float_as_uint(xv) & (k < a.d_in ? 0xffffffffu : 0u));
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            unsigned d[P];
-            S::template split_pair<false>(v[2 * q], v[2 * q + 1], d);
-#pragma unroll
-            for (int p = 0; p < P; ++p) xB.p[p][q] = d[p];
-        }
+        for (int j = 0; j < 8; ++j) xv[j] = xr[min(8 * half + j, a.d_in - 1)];
     }
     uint32_t tval[2] = {0u, 0u}, epval[2] = {0u, 0u};
     float b3v[2][kQ];
@@ -1792,8 +1770,41 @@ __global__ void __launch_bounds__(256, 2) mlp3_rt16_kernel(const float *x, int E
             b3v[it][i] = j < a.nout ? v : 0.0f;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's loads and its pieces of the first three super-stages
-    __syncthreads();                                               // ... and everybody else's: biases, W3 and the ring are in LDS
+    dma_super(1);
+    dma_super(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // the tables -> LDS (the W3 rows carry 1 / (layer 2's weight factor), a power of two)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = tid + 256 * u;
+        if (i < total) {
+            const bool l1 = i < nc1 * 32;
+            const int j = l1 ? i : i - nc1 * 32, h = l1 ? a.h1 : a.h2;
+            sb1[i] = __uint_as_float(__float_as_uint(bv[u]) & (j < h ? 0xffffffffu : 0u)) * (l1 ? ws1 : ws2);
+            if constexpr (VL3) {
+                if (!l1) {
+                    f32x4 w;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) w[o] = __uint_as_float(__float_as_uint(wv[u][o]) & ((j < a.h2 && o < a.nout) ? 0xffffffffu : 0u)) * wi2;
+                    sw3[j] = w;
+                }
+            }
+        }
+    }
+    // the x operand of layer 1 (one 16-wide k-step, linear order: inputs 8 half + j of row lane & 31), split once
+    Parts<P> xB;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float v2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) v2[t] = __uint_as_float(__float_as_uint(xv[2 * q + t]) & (8 * half + 2 * q + t < a.d_in ? 0xffffffffu : 0u));
+        unsigned d[P];
+        S::template split_pair<false>(v2[0], v2[1], d);
+#pragma unroll
+        for (int p = 0; p < P; ++p) xB.p[p][q] = d[p];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's table entries are in LDS (its pieces of super-stage 0 as well)
+    __builtin_amdgcn_s_barrier();                                  // ... and everybody else's
     PT64(1);
 
     // ---- consumption.  wf[0..3] = the current block's pieces (k-step 0 hi, lo; k-step 1 hi, lo); a piece is re-read with the NEXT

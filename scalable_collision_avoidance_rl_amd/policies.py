@@ -275,6 +275,8 @@ class BatchedMLP:
         `DroneMlp.w2_layout = 2`: the row-tile kernel of round 6; d_in <= 14), "fragments" layer 2 as matrix-core fragments
         (`pack_f32_fragments`, `w2_layout = 1`: the kernel of rounds 3-5); False keeps the [N, h1, h2] array of the plain C ABI
         (`w2_layout = 0`).
+        ``split_kernel`` (f16x2 only): False (default) runs the row-tile kernel of round 6 (`dronesim_mlp_forward_f16x2_rt`: ONE
+        stream per agent, `pack_f16_rowtile_stream`), True the split kernel of rounds 2-5 (`dronesim_mlp_forward_f16x2`).
         NOTE: the packed images are SNAPSHOTS of the weights: after an in-place update of ``w1 .. b3`` call
         `refresh_weights()` (re-packs into the same device buffers)."""
         import torch

@@ -61,3 +61,15 @@ for rname, idx in rounds.items():
         d = tt[:, :, k] - prev
         prev = tt[:, :, k]
         print(f"  {names.get(k, str(k)):>22}: median {np.median(d):8.0f}  p5 {np.percentile(d, 5):8.0f}  p95 {np.percentile(d, 95):8.0f}")
+
+# where the workgroups ran (stamp 34 = HW_ID | XCC_ID << 32 of each wave)
+from collections import Counter, defaultdict
+hw = t[:, :, 34].astype(np.int64)
+simd, cu, sh, se, xcc = (hw >> 4) & 3, (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7, (hw >> 32) & 15
+cukey = (xcc * 10000 + se * 1000 + sh * 100 + cu)[:, 0]
+by_cu = defaultdict(list)
+for b in order[:512]:
+    by_cu[cukey[b]].append(int(b))
+gaps = Counter(abs((v[0] >> 3) - (v[1] >> 3)) for v in by_cu.values() if len(v) == 2)
+print(f" first round: {len(by_cu)} CUs hold {sum(len(v) for v in by_cu.values())} workgroups; co-resident pairs differ in blockIdx >> 3 by {dict(gaps)}; "
+      f"a workgroup's four waves sit on {Counter(len(set(simd[b])) for b in order[:512]).most_common(1)[0][0]} different SIMDs")
