@@ -10,6 +10,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+if len(sys.argv) > 3 and sys.argv[3] == "f32":                       # the stamps live in the LDS-staged f32 kernel (the row-tile kernels: trace_rt16.py)
+    os.environ.setdefault("PB_PACK", "fragments")
 from scalable_collision_avoidance_rl_amd import _native, drones
 from tools.kbench import PRESETS
 from tools.pbench import rnd_policy
